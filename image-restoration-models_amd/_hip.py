@@ -1,0 +1,119 @@
+"""ctypes binding of libirm_hip.so (C ABI: include/irm_hip.h).
+
+The product path has no CPU fallback: if the library is missing, or a call is
+rejected, this module raises.  Tensors are passed as raw device pointers, work
+is enqueued on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libirm_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
+LN_NONE, LN_WITHBIAS, LN_BIASFREE = 0, 1, 2
+
+_P, _L, _I, _F = C.c_void_p, C.c_long, C.c_int, C.c_float
+
+#: symbol -> argtypes, mirrors include/irm_hip.h one to one
+SIGNATURES = {
+    "irm_version": [],
+    "irm_ln_stats_f32": [_P, _L, _P, _I, _I, _I, _F, _P],
+    "irm_gemm1x1_f32": [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "irm_dwconv3x3_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
+    "irm_dwconv3x3_gate_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "irm_mdta_gram_f32": [_P, _L, _P, _I, _I, _I, _I, _I, _P],
+    "irm_mdta_finalize_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "irm_conv3x3_f32": [_P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "irm_tile_extract": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P],
+    "irm_window_blend": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P],
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libirm_hip.so once; raise HipLibraryError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C image-restoration-models_amd/csrc).  There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = _I
+        _lib = lib
+    return _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    assert t.is_cuda, "HIP kernels need device tensors"
+    return t.data_ptr()
+
+
+def call(name: str, *args):
+    """Invoke a C-ABI entry point on the current stream; raise on a non-zero status."""
+    rc = getattr(load(), name)(*args, _stream())
+    if rc != 0:
+        raise HipLibraryError(f"{name} failed with status {rc} "
+                              f"({'invalid arguments' if rc == -1 else 'HIP launch error'})")
+
+
+# ---------------------------------------------------------------------------
+# host-side weight packing (MFMA B-operand order, see include/irm_hip.h)
+# ---------------------------------------------------------------------------
+
+def pack_gemm_weight(w: torch.Tensor) -> torch.Tensor:
+    """W [M][K] -> wp[ceil(M/16)][4*ceil(K/16)][64], wp[mt][ks][l] = W[16mt+(l&15)][4ks+(l>>4)]."""
+    w = w.detach().reshape(w.shape[0], -1).float()
+    m, k = w.shape
+    mt, ks = (m + 15) // 16, 4 * ((k + 15) // 16)
+    wpad = torch.zeros(mt * 16, ks * 4, dtype=torch.float32, device=w.device)
+    wpad[:m, :k] = w
+    # [mt][16 r][ks][4 g] -> [mt][ks][g][r]  (lane = g*16 + r)
+    return wpad.view(mt, 16, ks, 4).permute(0, 2, 3, 1).contiguous().view(-1)
+
+
+def pack_conv3x3_weight(w: torch.Tensor) -> torch.Tensor:
+    """W [Co][Ci][3][3] -> wp[9][ceil(Co/16)][2*ceil(Ci/8)][64]."""
+    w = w.detach().float()
+    co, ci = w.shape[:2]
+    mt, ks = (co + 15) // 16, 2 * ((ci + 7) // 8)
+    wpad = torch.zeros(9, mt * 16, ks * 4, dtype=torch.float32, device=w.device)
+    wpad[:, :co, :ci] = w.reshape(co, ci, 9).permute(2, 0, 1)
+    return wpad.view(9, mt, 16, ks, 4).permute(0, 1, 3, 4, 2).contiguous().view(-1)
+
+
+def deconv_as_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d(k3,s1,p1) weight [Ci][Co][3][3] -> equivalent Conv2d weight [Co][Ci][3][3]
+    (rednet.py:46-60): transpose the channel axes and flip both spatial axes."""
+    return w.detach().transpose(0, 1).flip(-1, -2).contiguous()
+
+
+def choose_ct(mtiles: int, options=(9, 8, 6, 4, 3)) -> int:
+    """Output-channel tiles per pass: least padding, then the largest tile."""
+    best = None
+    for ct in options:
+        waste = -(-mtiles // ct) * ct - mtiles
+        if best is None or waste < best[0]:
+            best = (waste, ct)
+    return best[1]

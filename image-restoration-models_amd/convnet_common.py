@@ -1,0 +1,42 @@
+"""Shared driver for the plain conv3x3 stacks (DnCNN, REDNet) on the HIP conv kernel."""
+from __future__ import annotations
+
+import torch
+
+from . import _hip
+
+
+def conv3x3(wp, x, y, ci, co, bias=None, relu1=False, res=None, res_mode=0, relu2=False):
+    """y = epilogue(conv3x3(x)) through irm_conv3x3_f32 (include/irm_hip.h)."""
+    B, _, H, W = x.shape
+    mt = (co + 15) // 16
+    ct = _hip.choose_ct(mt, (6, 4, 3, 2, 1))
+    nchunks = -(-mt // ct)
+    blocks = -(-W // 32) * -(-H // 8) * B
+    yg = max(1, min(nchunks, -(-1024 // blocks)))
+    _hip.call("irm_conv3x3_f32", _hip.ptr(wp), _hip.ptr(x), x.stride(0), _hip.ptr(y), y.stride(0),
+              _hip.ptr(res), res.stride(0) if res is not None else 0, _hip.ptr(bias), B, ci, co, H, W,
+              int(relu1), res_mode, int(relu2), 0, ct, yg)
+
+
+class PackedCache:
+    """Rebuilds packed weights when the parameters of `module` change."""
+
+    def __init__(self, module, build):
+        self.module, self.build, self.key, self.value = module, build, None, None
+
+    def get(self):
+        ver, dev = 0, None
+        for p in self.module.parameters():
+            dev = p.device
+            ver += p._version + (p.data_ptr() & 0xFFFF)
+        key = (str(dev), ver)
+        if self.value is None or key != self.key:
+            self.value, self.key = self.build(), key
+        return self.value
+
+
+def require_cuda(x, what):
+    if not x.is_cuda:
+        raise _hip.HipLibraryError(f"irm_amd {what} runs on the GPU only (no CPU fallback); "
+                                   "move the model and input to 'cuda'")

@@ -1,0 +1,176 @@
+// HBM-bound planar-NCHW kernels: per-pixel LayerNorm statistics and the
+// depth-wise 3x3 convolutions (plain and GDFN-gated).
+#include "irm_common.h"
+
+// ---------------------------------------------------------------------------
+// LayerNorm statistics over the channel axis (restormer.py:25-70): per pixel
+// mean and rstd = 1/sqrt(biased var + eps).  One thread owns 4 consecutive
+// pixels (16-byte loads, a wave reads 1 KiB per channel row) and runs Welford
+// over the C rows, so x is read exactly once.
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, long x_bs,
+                                                       float* __restrict__ stats, int C, int N, float eps) {
+    const int b = blockIdx.y;
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (n >= N) return;
+    const float* p = x + (long)b * x_bs + n;
+    float4 mean = make_float4(0.f, 0.f, 0.f, 0.f), m2 = mean;
+    for (int c = 0; c < C; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (long)c * N);
+        const float rc = 1.0f / (float)(c + 1);
+        float d;
+        d = v.x - mean.x; mean.x += d * rc; m2.x += d * (v.x - mean.x);
+        d = v.y - mean.y; mean.y += d * rc; m2.y += d * (v.y - mean.y);
+        d = v.z - mean.z; mean.z += d * rc; m2.z += d * (v.z - mean.z);
+        d = v.w - mean.w; mean.w += d * rc; m2.w += d * (v.w - mean.w);
+    }
+    const float inv = 1.0f / (float)C;
+    float4 rstd;
+    rstd.x = 1.0f / sqrtf(m2.x * inv + eps);
+    rstd.y = 1.0f / sqrtf(m2.y * inv + eps);
+    rstd.z = 1.0f / sqrtf(m2.z * inv + eps);
+    rstd.w = 1.0f / sqrtf(m2.w * inv + eps);
+    float* s = stats + (long)b * 2 * N;
+    *reinterpret_cast<float4*>(s + n) = mean;
+    *reinterpret_cast<float4*>(s + N + n) = rstd;
+}
+
+extern "C" int irm_ln_stats_f32(const float* x, long x_bs, float* stats, int B, int C, int N, float eps,
+                                hipStream_t stream) {
+    if (!x || !stats || B <= 0 || C <= 0 || N <= 0 || (N & 3) || (x_bs & 3) || B > 65535) return IRM_EINVAL;
+    dim3 grid((N / 4 + 255) / 256, B);
+    hipLaunchKernelGGL(ln_stats_kernel, grid, dim3(256), 0, stream, x, x_bs, stats, C, N, eps);
+    return irm_launch_status();
+}
+
+// ---------------------------------------------------------------------------
+// Depth-wise 3x3, zero pad 1 (restormer.py:84,106; MaIR conv2d with bias+SiLU).
+// A work item = 4 consecutive columns x RS rows of one channel plane; a
+// 3-row register window slides down the strip so each input row is loaded once
+// per strip (halo rows come from L2).  GATE fuses the GDFN gate
+// (restormer.py:89-91): out[c] = gelu(dw(x[c])) * dw(x[c + hid]).
+struct DwArgs {
+    const float* x; long x_bs;
+    const float* w;        // [C][9]
+    const float* bias;     // [C] or null
+    float* y; long y_bs;
+    int C;                 // output channels (GATE: hid; input has 2*hid)
+    int H, W, act;
+};
+
+__device__ __forceinline__ void dw_load_row(const float* plane, int row, int H, int W, int col, float (&r)[6]) {
+    if (row < 0 || row >= H) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = 0.0f;
+        return;
+    }
+    const float* p = plane + (long)row * W + col;
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    r[0] = col > 0 ? p[-1] : 0.0f;
+    r[1] = v.x; r[2] = v.y; r[3] = v.z; r[4] = v.w;
+    r[5] = col + 4 < W ? p[4] : 0.0f;
+}
+
+__device__ __forceinline__ float4 dw_apply(const float (&k)[9], const float (&r0)[6], const float (&r1)[6],
+                                           const float (&r2)[6], float bias) {
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float s = bias;
+        s += k[0] * r0[i] + k[1] * r0[i + 1] + k[2] * r0[i + 2];
+        s += k[3] * r1[i] + k[4] * r1[i + 1] + k[5] * r1[i + 2];
+        s += k[6] * r2[i] + k[7] * r2[i + 1] + k[8] * r2[i + 2];
+        o[i] = s;
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+template <bool GATE, int RS>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs a) {
+    const int cgs = a.W >> 2;
+    const int strips = (a.H + RS - 1) / RS;
+    const long total = (long)a.C * strips * cgs;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cg = (int)(idx % cgs);
+    const long t = idx / cgs;
+    const int strip = (int)(t % strips);
+    const int c = (int)(t / strips);
+    const int b = blockIdx.y;
+    const int col = cg * 4;
+    const int y0 = strip * RS;
+    const long plane = (long)a.H * a.W;
+
+    const float* xa = a.x + (long)b * a.x_bs + (long)c * plane;
+    float ka[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ka[i] = a.w[c * 9 + i];
+    const float ba = a.bias ? a.bias[c] : 0.0f;
+
+    const float* xb = nullptr;
+    float kb[9];
+    float bb = 0.0f;
+    if (GATE) {
+        xb = xa + (long)a.C * plane;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) kb[i] = a.w[(c + a.C) * 9 + i];
+        bb = a.bias ? a.bias[c + a.C] : 0.0f;
+    }
+    float* yo = a.y + (long)b * a.y_bs + (long)c * plane;
+
+    float a0[6], a1[6], a2[6], b0[6], b1[6], b2[6];
+    dw_load_row(xa, y0 - 1, a.H, a.W, col, a0);
+    dw_load_row(xa, y0, a.H, a.W, col, a1);
+    if (GATE) {
+        dw_load_row(xb, y0 - 1, a.H, a.W, col, b0);
+        dw_load_row(xb, y0, a.H, a.W, col, b1);
+    }
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        const int y = y0 + r;
+        if (y >= a.H) break;
+        dw_load_row(xa, y + 1, a.H, a.W, col, a2);
+        float4 o = dw_apply(ka, a0, a1, a2, ba);
+        if (GATE) {
+            dw_load_row(xb, y + 1, a.H, a.W, col, b2);
+            const float4 g = dw_apply(kb, b0, b1, b2, bb);
+            o.x = irm_gelu(o.x) * g.x; o.y = irm_gelu(o.y) * g.y;
+            o.z = irm_gelu(o.z) * g.z; o.w = irm_gelu(o.w) * g.w;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { b0[i] = b1[i]; b1[i] = b2[i]; }
+        } else if (a.act != IRM_ACT_NONE) {
+            o.x = irm_act(o.x, a.act); o.y = irm_act(o.y, a.act);
+            o.z = irm_act(o.z, a.act); o.w = irm_act(o.w, a.act);
+        }
+        *reinterpret_cast<float4*>(yo + (long)y * a.W + col) = o;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { a0[i] = a1[i]; a1[i] = a2[i]; }
+    }
+}
+
+static int dw_launch(bool gate, const DwArgs& a, int B, hipStream_t stream) {
+    constexpr int RS = 8;
+    const long total = (long)a.C * ((a.H + RS - 1) / RS) * (a.W >> 2);
+    const long blocks = (total + 255) / 256;
+    if (blocks > 2147483647L || B > 65535) return IRM_EINVAL;
+    dim3 grid((unsigned)blocks, B);
+    if (gate) hipLaunchKernelGGL((dwconv3x3_kernel<true, RS>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((dwconv3x3_kernel<false, RS>), grid, dim3(256), 0, stream, a);
+    return irm_launch_status();
+}
+
+extern "C" int irm_dwconv3x3_f32(const float* x, long x_bs, const float* w, const float* bias, float* y,
+                                 long y_bs, int B, int C, int H, int W, int act, hipStream_t stream) {
+    if (!x || !w || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3) || (x_bs & 3) || (y_bs & 3))
+        return IRM_EINVAL;
+    if (act < 0 || act > 3) return IRM_EINVAL;
+    DwArgs a{x, x_bs, w, bias, y, y_bs, C, H, W, act};
+    return dw_launch(false, a, B, stream);
+}
+
+extern "C" int irm_dwconv3x3_gate_f32(const float* x, long x_bs, const float* w, const float* bias, float* y,
+                                      long y_bs, int B, int hid, int H, int W, hipStream_t stream) {
+    if (!x || !w || !y || B <= 0 || hid <= 0 || H <= 0 || W <= 0 || (W & 3) || (x_bs & 3) || (y_bs & 3))
+        return IRM_EINVAL;
+    DwArgs a{x, x_bs, w, bias, y, y_bs, hid, H, W, IRM_ACT_NONE};
+    return dw_launch(true, a, B, stream);
+}

@@ -1,0 +1,43 @@
+// Shared helpers for the gfx950 kernels of libirm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define IRM_OK 0
+#define IRM_EINVAL (-1)
+#define IRM_ELAUNCH (-2)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// activation codes shared by the GEMM / conv epilogues
+#define IRM_ACT_NONE 0
+#define IRM_ACT_RELU 1
+#define IRM_ACT_GELU 2   // exact erf GELU (torch F.gelu default)
+#define IRM_ACT_SILU 3
+
+// LayerNorm prologue modes (restormer.py:25-70)
+#define IRM_LN_NONE 0
+#define IRM_LN_WITHBIAS 1
+#define IRM_LN_BIASFREE 2
+
+static inline int irm_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? IRM_OK : IRM_ELAUNCH;
+}
+
+__device__ __forceinline__ float irm_gelu(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float irm_act(float v, int act) {
+    if (act == IRM_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == IRM_ACT_GELU) return irm_gelu(v);
+    if (act == IRM_ACT_SILU) return v / (1.0f + __expf(-v));
+    return v;
+}
+
+// D(16x16) += A(16x4) * B(4x16), exact f32.  Lane l supplies A[l&15][l>>4] and
+// B[l>>4][l&15]; it receives D[(l>>4)*4 + r][l&15] in element r of the result.
+__device__ __forceinline__ f32x4 irm_mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}

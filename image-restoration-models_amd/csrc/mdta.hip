@@ -1,0 +1,249 @@
+// MDTA core (src/restormer/restormer.py:115-129): transposed (channel)
+// attention.  The reference L2-normalises q and k along HW, forms the c x c
+// logits per head, softmaxes the rows and multiplies by v, then applies the
+// 1x1 project_out.  Here:
+//
+//   pass 1 (irm_mdta_gram_f32)    raw Gram G = q k^T and the squared row norms
+//                                 of q and k, accumulated over HW in one sweep
+//                                 of q,k on the exact-f32 MFMA; per-chunk
+//                                 partials go to a workspace (no atomics).
+//   pass 2 (irm_mdta_finalize_f32) fixed-order reduction of the partials,
+//                                 A = softmax_j(G_ij/(max(|q_i|,eps) max(|k_j|,eps)) * temperature),
+//                                 folded with project_out into ONE C x C matrix
+//                                 per image, Mfold = W_out * blockdiag(A_heads),
+//                                 written in the packed layout of gemm_pw.hip.
+//   pass 3 = irm_gemm1x1_f32(Mfold, v, residual x): attn@v, project_out and the
+//            residual add in one GEMM.
+//
+// Gram kernel mapping: one WAVE = one (batch, head, 16*SB x 16*SB sub-block of
+// G, chunk of HW).  HW is the MFMA reduction axis; any bijection between HW
+// positions and (k-step, k-slot) is legal as long as q and k use the same one,
+// so each lane loads 16-byte pieces straight from global memory: lane (r, g)
+// of load j reads row r, positions slab + 16 j + 4 g .. +3, and the 4 elements
+// feed 4 successive MFMAs.  No LDS, no barriers.
+#include "irm_common.h"
+
+struct GramArgs {
+    const float* qkv; long bs;     // [B][3C][N]; q rows [0,C), k rows [C,2C)
+    float* part;                   // [B][heads][nchunk][c*c + 2c]
+    int C, heads, N, chunk, nchunk;
+};
+
+template <int SB>
+__global__ __launch_bounds__(256) void mdta_gram_kernel(GramArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int c = a.C / a.heads;
+    const int nsb = c / (16 * SB);                 // sub-blocks per side
+    const int nsub = nsb * nsb;
+    // unit id: sub-block fastest so that waves sharing q/k rows sit in one workgroup
+    const long unit = (long)blockIdx.x * 4 + wave;
+    const long units_per_bh = (long)nsub * a.nchunk;
+    const long total = (long)gridDim.y * a.heads * units_per_bh;
+    const int b = blockIdx.y;
+    if (unit >= a.heads * units_per_bh) return;
+    (void)total;
+    const int head = (int)(unit / units_per_bh);
+    const long rem = unit % units_per_bh;
+    const int chunk_id = (int)(rem / nsub);
+    const int sub = (int)(rem % nsub);
+    const int si = sub / nsb, sj = sub % nsb;
+
+    const int r = lane & 15, g = lane >> 4;
+    const float* q = a.qkv + (long)b * a.bs + (long)(head * c + si * 16 * SB + r) * a.N;
+    const float* k = a.qkv + (long)b * a.bs + (long)(a.C + head * c + sj * 16 * SB + r) * a.N;
+
+    f32x4 acc[SB][SB];
+    float nq[SB], nk[SB];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+        nq[i] = 0.f; nk[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < SB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int nbeg = chunk_id * a.chunk;
+    const int nend = min(nbeg + a.chunk, a.N);
+    for (int slab = nbeg; slab < nend; slab += 64) {
+        float4 qa[SB][4], ka[SB][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = slab + 16 * j + 4 * g;
+            const bool ok = n < nend;             // N, chunk are multiples of 4
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                qa[i][j] = ok ? *reinterpret_cast<const float4*>(q + (long)i * 16 * a.N + n)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                ka[i][j] = ok ? *reinterpret_cast<const float4*>(k + (long)i * 16 * a.N + n)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                nq[i] += qa[i][j].x * qa[i][j].x + qa[i][j].y * qa[i][j].y + qa[i][j].z * qa[i][j].z +
+                         qa[i][j].w * qa[i][j].w;
+                nk[i] += ka[i][j].x * ka[i][j].x + ka[i][j].y * ka[i][j].y + ka[i][j].z * ka[i][j].z +
+                         ka[i][j].w * ka[i][j].w;
+            }
+#pragma unroll
+            for (int ii = 0; ii < SB; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < SB; ++jj) {
+                    acc[ii][jj] = irm_mfma16(qa[ii][j].x, ka[jj][j].x, acc[ii][jj]);
+                    acc[ii][jj] = irm_mfma16(qa[ii][j].y, ka[jj][j].y, acc[ii][jj]);
+                    acc[ii][jj] = irm_mfma16(qa[ii][j].z, ka[jj][j].z, acc[ii][jj]);
+                    acc[ii][jj] = irm_mfma16(qa[ii][j].w, ka[jj][j].w, acc[ii][jj]);
+                }
+        }
+    }
+
+    // partial record of this (b, head, chunk): G[c][c], nq[c], nk[c]
+    const long rec = (long)c * c + 2 * c;
+    float* out = a.part + (((long)b * a.heads + head) * a.nchunk + chunk_id) * rec;
+#pragma unroll
+    for (int ii = 0; ii < SB; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < SB; ++jj) {
+            const int col = sj * 16 * SB + jj * 16 + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = si * 16 * SB + ii * 16 + g * 4 + e;
+                out[(long)row * c + col] = acc[ii][jj][e];
+            }
+        }
+    // squared norms: sum the 4 lane groups (lanes r, r+16, r+32, r+48)
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+        float vq = nq[i], vk = nk[i];
+        vq += __shfl_xor(vq, 16); vq += __shfl_xor(vq, 32);
+        vk += __shfl_xor(vk, 16); vk += __shfl_xor(vk, 32);
+        if (g == 0) {
+            if (sj == 0) out[(long)c * c + si * 16 * SB + i * 16 + r] = vq;
+            if (si == 0) out[(long)c * c + c + sj * 16 * SB + i * 16 + r] = vk;
+        }
+    }
+}
+
+extern "C" int irm_mdta_gram_f32(const float* qkv, long bs, float* part, int B, int C, int heads, int N,
+                                 int chunk, hipStream_t stream) {
+    if (!qkv || !part || B <= 0 || C <= 0 || heads <= 0 || N <= 0 || chunk <= 0) return IRM_EINVAL;
+    if (C % heads || (N & 3) || (chunk & 63) || (bs & 3) || B > 65535) return IRM_EINVAL;
+    const int c = C / heads;
+    if (c % 16) return IRM_EINVAL;
+    GramArgs a{qkv, bs, part, C, heads, N, chunk, (N + chunk - 1) / chunk};
+    const int sb = (c % 48 == 0) ? 3 : (c % 32 == 0) ? 2 : 1;
+    const int nsb = c / (16 * sb);
+    const long units = (long)heads * nsb * nsb * a.nchunk;
+    dim3 grid((unsigned)((units + 3) / 4), B);
+    if (sb == 3) hipLaunchKernelGGL((mdta_gram_kernel<3>), grid, dim3(256), 0, stream, a);
+    else if (sb == 2) hipLaunchKernelGGL((mdta_gram_kernel<2>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((mdta_gram_kernel<1>), grid, dim3(256), 0, stream, a);
+    return irm_launch_status();
+}
+
+// ---------------------------------------------------------------------------
+// reduce: fixed-order sum of the per-chunk partial records.  A workgroup owns
+// 64 consecutive record elements; its 4 waves each sum every 4th chunk and the
+// four sums are combined in wave order through LDS, so the result does not
+// depend on scheduling.
+__global__ __launch_bounds__(256) void mdta_reduce_kernel(const float* __restrict__ part,
+                                                          float* __restrict__ gsum, int rec, int nchunk) {
+    __shared__ float sm[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    const long bh = blockIdx.y;
+    float s = 0.0f;
+    if (e < rec) {
+        const float* p = part + bh * nchunk * (long)rec + e;
+        for (int ch = w; ch < nchunk; ch += 4) s += p[(long)ch * rec];
+    }
+    sm[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && e < rec) {
+        const int l = threadIdx.x;
+        gsum[bh * rec + e] = ((sm[0][l] + sm[1][l]) + sm[2][l]) + sm[3][l];
+    }
+}
+
+// finalize: one workgroup per (batch, head).
+//  1. one thread per row: logits, max, exp, sum -> A row in LDS;
+//  2. Mfold[co][head*c + j] = sum_i Wout[co][head*c + i] * A[i][j], stored packed:
+//     Wp[mtile][kstep][lane] = Mfold[16 mtile + (lane&15)][4 kstep + (lane>>4)].
+struct FinArgs {
+    const float* gsum;          // [B][heads][c*c + 2c]
+    const float* temperature;   // [heads]
+    const float* wout;          // [C][C] project_out weight (row-major, [co][ci])
+    float* mfold;               // [B][mtiles][ksteps][64]
+    float* attn;                // optional [B][heads][c][c] (tests) or null
+    int C, heads, ksteps;
+};
+
+__global__ __launch_bounds__(256) void mdta_finalize_kernel(FinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int c = a.C / a.heads;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int rec = c * c + 2 * c;
+    float* G = sm;                 // [c][c], overwritten by A
+    float* nrm = sm + c * c;       // [2c] squared norms of q rows, k rows
+    const float* p = a.gsum + ((long)b * a.heads + head) * rec;
+    for (int e = threadIdx.x; e < rec; e += 256) sm[e] = p[e];
+    __syncthreads();
+    const float temp = a.temperature[head];
+    for (int i = threadIdx.x; i < c; i += 256) {
+        const float qi = fmaxf(sqrtf(nrm[i]), 1e-12f);
+        float m = -INFINITY;
+        for (int j = 0; j < c; ++j) {
+            const float kj = fmaxf(sqrtf(nrm[c + j]), 1e-12f);
+            const float l = G[i * c + j] / (qi * kj) * temp;
+            G[i * c + j] = l;
+            m = fmaxf(m, l);
+        }
+        float s = 0.0f;
+        for (int j = 0; j < c; ++j) {
+            const float e = expf(G[i * c + j] - m);
+            G[i * c + j] = e;
+            s += e;
+        }
+        const float inv = 1.0f / s;
+        for (int j = 0; j < c; ++j) G[i * c + j] *= inv;
+    }
+    __syncthreads();
+    if (a.attn) {
+        float* o = a.attn + ((long)b * a.heads + head) * c * c;
+        for (int e = threadIdx.x; e < c * c; e += 256) o[e] = G[e];
+    }
+    const int mtiles = (a.C + 15) / 16;
+    float* mf = a.mfold + (long)b * mtiles * a.ksteps * 64;
+    for (int e = threadIdx.x; e < a.C * c; e += 256) {
+        const int co = e / c, j = e % c;
+        const float* wrow = a.wout + (long)co * a.C + head * c;
+        float s = 0.0f;
+        for (int i = 0; i < c; ++i) s += wrow[i] * G[i * c + j];
+        const int kcol = head * c + j;
+        const int lane = (co & 15) + 16 * (kcol & 3);
+        mf[((long)(co >> 4) * a.ksteps + (kcol >> 2)) * 64 + lane] = s;
+    }
+}
+
+extern "C" int irm_mdta_finalize_f32(const float* part, float* gsum, const float* temperature,
+                                     const float* wout, float* mfold, float* attn, int B, int C, int heads,
+                                     int nchunk, hipStream_t stream) {
+    if (!part || !gsum || !temperature || !wout || !mfold || B <= 0 || C <= 0 || heads <= 0 || nchunk <= 0)
+        return IRM_EINVAL;
+    if (C % heads || (long)B * heads > 65535) return IRM_EINVAL;
+    const int c = C / heads;
+    const int rec = c * c + 2 * c;
+    const size_t lds = (size_t)rec * sizeof(float);
+    if (lds > 64 * 1024) return IRM_EINVAL;
+    hipLaunchKernelGGL(mdta_reduce_kernel, dim3((rec + 63) / 64, B * heads), dim3(256), 0, stream, part, gsum,
+                       rec, nchunk);
+    int rc = irm_launch_status();
+    if (rc != IRM_OK) return rc;
+    // padded rows/cols of the packed matrix stay zero: the caller clears mfold once at allocation
+    // (C is a multiple of 16 at every Restormer level, so normally there is no padding at all)
+    FinArgs a{gsum, temperature, wout, mfold, attn, C, heads, 4 * ((C + 15) / 16)};
+    hipLaunchKernelGGL(mdta_finalize_kernel, dim3(heads, B), dim3(256), lds, stream, a);
+    return irm_launch_status();
+}

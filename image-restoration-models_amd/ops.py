@@ -1,0 +1,120 @@
+"""Tensor-level wrappers of the C ABI (include/irm_hip.h).
+
+Activations are float32 CUDA tensors shaped [B, C, H, W]; the channel and pixel
+axes must be dense (stride(1) == H*W, stride(3) == 1) while the batch stride is
+free, so channel slices of a larger buffer (``buf[:, a:b]``) are valid inputs and
+outputs.  All calls are asynchronous on torch's current stream.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _hip
+from ._hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU, LN_BIASFREE, LN_NONE, LN_WITHBIAS  # noqa: F401
+
+
+def _chk(t: torch.Tensor, name: str):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4):
+        raise ValueError(f"{name}: expected a float32 CUDA tensor [B,C,H,W]")
+    _, c, h, w = t.shape
+    if t.stride(3) != 1 or t.stride(2) != w or (c > 1 and t.stride(1) != h * w):
+        raise ValueError(f"{name}: channel/pixel axes must be dense (got strides {t.stride()})")
+    return t
+
+
+def _bs(t):
+    return t.stride(0) if t is not None else 0
+
+
+def target_blocks() -> int:
+    """Workgroups wanted per launch: 4 per CU on the 256-CU MI355X."""
+    return 1024
+
+
+def ln_stats(x: torch.Tensor, stats: torch.Tensor, eps: float = 1e-5):
+    """stats[b,0,n] = mean over channels, stats[b,1,n] = rstd (restormer.py:25-70)."""
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    assert stats.numel() >= B * 2 * H * W and stats.is_contiguous()
+    _hip.call("irm_ln_stats_f32", _hip.ptr(x), _bs(x), _hip.ptr(stats), B, C, H * W, float(eps))
+
+
+def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, *, res=None, bias=None,
+            stats=None, lnw=None, lnb=None, ln_mode=LN_NONE, act=ACT_NONE, w_bs: int = 0, ct: int | None = None,
+            ygroups: int | None = None):
+    """y = act(W @ LN(x) + bias) (+ res); wp from _hip.pack_gemm_weight."""
+    _chk(x, "x"), _chk(y, "y")
+    B, _, H, W = x.shape
+    N = H * W
+    assert x.shape[1] >= K and y.shape[1] >= M
+    if res is not None:
+        _chk(res, "res")
+    mt = (M + 15) // 16
+    if ct is None:
+        ct = _hip.choose_ct(mt)
+    if ygroups is None:
+        nchunks = -(-mt // ct)
+        blocks = -(-N // 128) * B
+        ygroups = max(1, min(nchunks, -(-target_blocks() // blocks)))
+    _hip.call("irm_gemm1x1_f32", _hip.ptr(wp), int(w_bs), _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y),
+              _hip.ptr(res), _bs(res), _hip.ptr(bias), _hip.ptr(stats), _hip.ptr(lnw), _hip.ptr(lnb),
+              int(ln_mode), int(act), B, M, K, N, ct, ygroups)
+
+
+def dwconv3x3(x, w9, y, *, bias=None, act=ACT_NONE):
+    """Depth-wise 3x3 (+bias, +activation); w9: [C, 9]."""
+    _chk(x, "x"), _chk(y, "y")
+    B, C, H, W = x.shape
+    _hip.call("irm_dwconv3x3_f32", _hip.ptr(x), _bs(x), _hip.ptr(w9), _hip.ptr(bias), _hip.ptr(y), _bs(y),
+              B, C, H, W, int(act))
+
+
+def dwconv3x3_gate(x, w9, y, *, bias=None):
+    """GDFN: y[:, c] = gelu(dw(x[:, c])) * dw(x[:, c + hid]); x has 2*hid channels."""
+    _chk(x, "x"), _chk(y, "y")
+    B, C2, H, W = x.shape
+    _hip.call("irm_dwconv3x3_gate_f32", _hip.ptr(x), _bs(x), _hip.ptr(w9), _hip.ptr(bias), _hip.ptr(y), _bs(y),
+              B, C2 // 2, H, W)
+
+
+def mdta_plan(B: int, C: int, heads: int, N: int):
+    """(chunk, nchunk, record size) of the Gram pass for this problem size."""
+    c = C // heads
+    sb = 3 if c % 48 == 0 else 2 if c % 32 == 0 else 1
+    nsub = (c // (16 * sb)) ** 2
+    chunk = -(-(N * B * heads * nsub) // (4 * target_blocks()))
+    chunk = min(max(-(-chunk // 64) * 64, 256), 4096)
+    return chunk, -(-N // chunk), c * c + 2 * c
+
+
+def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, attn=None):
+    """Gram pass + finalize: mfold[b] <- packed(W_out @ blockdiag(softmax(...))) (restormer.py:115-131)."""
+    _chk(qkv, "qkv")
+    B, _, H, W = qkv.shape
+    N = H * W
+    chunk, nchunk, rec = mdta_plan(B, C, heads, N)
+    assert part.numel() >= B * heads * nchunk * rec and gsum.numel() >= B * heads * rec
+    _hip.call("irm_mdta_gram_f32", _hip.ptr(qkv), _bs(qkv), _hip.ptr(part), B, C, heads, N, chunk)
+    _hip.call("irm_mdta_finalize_f32", _hip.ptr(part), _hip.ptr(gsum), _hip.ptr(temperature), _hip.ptr(wout),
+              _hip.ptr(mfold), _hip.ptr(attn), B, C, heads, nchunk)
+
+
+def mfold_numel(C: int) -> int:
+    mt = (C + 15) // 16
+    return mt * 4 * mt * 64
+
+
+def conv3x3(wp, x, y, ci: int, co: int, *, bias=None, relu1=False, res=None, res_mode=0, relu2=False,
+            store_mode=0, ct: int | None = None, ygroups: int | None = None):
+    """Dense 3x3 conv with fused epilogue; store_mode 1 = PixelUnshuffle(2), 2 = PixelShuffle(2)."""
+    _chk(x, "x"), _chk(y, "y")
+    B, _, H, W = x.shape
+    mt = (co + 15) // 16
+    if ct is None:
+        ct = _hip.choose_ct(mt, (6, 4, 3, 2, 1))
+    if ygroups is None:
+        nchunks = -(-mt // ct)
+        blocks = -(-W // 32) * -(-H // 8) * B
+        ygroups = max(1, min(nchunks, -(-target_blocks() // blocks)))
+    _hip.call("irm_conv3x3_f32", _hip.ptr(wp), _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res),
+              _hip.ptr(bias), B, ci, co, H, W, int(relu1), int(res_mode), int(relu2), int(store_mode), ct, ygroups)

@@ -1,0 +1,311 @@
+"""Restormer forward on MI355X through libirm_hip.so.
+
+Drop-in for the reference's ``src/restormer/restormer.py`` (class ``Restormer``,
+same constructor keywords, same ``state_dict`` keys and shapes, ``model(x)``
+with x float32 NCHW on the GPU).  The sub-modules below only *hold* the
+parameters under the reference's names - they are never called; ``forward``
+drives the HIP kernels:
+
+  per TransformerBlock (restormer.py:137-150), activations planar NCHW, batch =
+  all tiles of one image:
+    ln_stats -> gemm1x1(qkv, LN prologue) -> dwconv3x3 -> mdta_gram ->
+    mdta_finalize (softmax + fold with project_out) -> gemm1x1(Mfold, v, +x)
+    ln_stats -> gemm1x1(project_in, LN prologue) -> dwconv3x3_gate ->
+    gemm1x1(project_out, +x)
+  and conv3x3 (patch embed, down/up-sampling with the pixel (un)shuffle folded
+  into the store, output conv + input residual).  The U-Net concatenations
+  (restormer.py:264-273) are not copies: producers write straight into channel
+  slices of the concat buffers.
+
+There is no PyTorch fallback: without the HIP library ``forward`` raises.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _hip, ops
+
+#: synthetic-weight rules (see synth.py): keep the restored image in range
+SYNTH_RULES = (
+    (r"^output\.weight$", "gain", 0.02),
+    (r"^skip_conv\.weight$", "gain", 0.5),
+)
+
+
+def _hidden(dim, factor):
+    return int(dim * factor)          # restormer.py:80
+
+
+class _Norm(nn.Module):
+    """Parameter holder with the reference's LayerNorm key layout (norm.body.weight/.bias)."""
+
+    def __init__(self, dim, kind):
+        super().__init__()
+        self.body = nn.Module()
+        self.body.weight = nn.Parameter(torch.ones(dim))
+        if kind != "BiasFree":
+            self.body.bias = nn.Parameter(torch.zeros(dim))
+        self.mode = _hip.LN_BIASFREE if kind == "BiasFree" else _hip.LN_WITHBIAS
+
+    @property
+    def w(self):
+        return self.body.weight
+
+    @property
+    def b(self):
+        return getattr(self.body, "bias", None)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads, bias):
+        super().__init__()
+        self.num_heads = num_heads
+        self.temperature = nn.Parameter(torch.ones(num_heads, 1, 1))
+        self.qkv = nn.Conv2d(dim, dim * 3, 1, bias=bias)
+        self.qkv_dwconv = nn.Conv2d(dim * 3, dim * 3, 3, padding=1, groups=dim * 3, bias=bias)
+        self.project_out = nn.Conv2d(dim, dim, 1, bias=bias)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, ffn_expansion_factor, bias):
+        super().__init__()
+        hid = _hidden(dim, ffn_expansion_factor)
+        self.hidden = hid
+        self.project_in = nn.Conv2d(dim, hid * 2, 1, bias=bias)
+        self.dwconv = nn.Conv2d(hid * 2, hid * 2, 3, padding=1, groups=hid * 2, bias=bias)
+        self.project_out = nn.Conv2d(hid, dim, 1, bias=bias)
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, dim, num_heads, ffn_expansion_factor, bias, LayerNorm_type):
+        super().__init__()
+        self.dim = dim
+        self.norm1 = _Norm(dim, LayerNorm_type)
+        self.attn = Attention(dim, num_heads, bias)
+        self.norm2 = _Norm(dim, LayerNorm_type)
+        self.ffn = FeedForward(dim, ffn_expansion_factor, bias)
+
+
+class _Proj(nn.Module):
+    def __init__(self, cin, cout, bias):
+        super().__init__()
+        self.proj = nn.Conv2d(cin, cout, 3, padding=1, bias=bias)
+
+
+class _Resample(nn.Module):
+    """Holder for Downsample / Upsample: key 'body.0.weight' (restormer.py:171-189)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.body = nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1, bias=False))
+
+
+def _stage(dim, heads, n, f, bias, ln):
+    return nn.Sequential(*[TransformerBlock(dim, heads, f, bias, ln) for _ in range(n)])
+
+
+class Restormer(nn.Module):
+    def __init__(self, inp_channels=3, out_channels=3, dim=48, num_blocks=(4, 6, 6, 8),
+                 num_refinement_blocks=4, heads=(1, 2, 4, 8), ffn_expansion_factor=2.66, bias=False,
+                 LayerNorm_type="WithBias", dual_pixel_task=False):
+        super().__init__()
+        f, ln = ffn_expansion_factor, LayerNorm_type
+        d1, d2, d3, d4 = dim, dim * 2, dim * 4, dim * 8
+        self.inp_channels, self.out_channels, self.dim = inp_channels, out_channels, dim
+        self.patch_embed = _Proj(inp_channels, d1, bias=False)
+        self.encoder_level1 = _stage(d1, heads[0], num_blocks[0], f, bias, ln)
+        self.down1_2 = _Resample(d1, d1 // 2)
+        self.encoder_level2 = _stage(d2, heads[1], num_blocks[1], f, bias, ln)
+        self.down2_3 = _Resample(d2, d2 // 2)
+        self.encoder_level3 = _stage(d3, heads[2], num_blocks[2], f, bias, ln)
+        self.down3_4 = _Resample(d3, d3 // 2)
+        self.latent = _stage(d4, heads[3], num_blocks[3], f, bias, ln)
+        self.up4_3 = _Resample(d4, d4 * 2)
+        self.reduce_chan_level3 = nn.Conv2d(d4, d3, 1, bias=bias)
+        self.decoder_level3 = _stage(d3, heads[2], num_blocks[2], f, bias, ln)
+        self.up3_2 = _Resample(d3, d3 * 2)
+        self.reduce_chan_level2 = nn.Conv2d(d3, d2, 1, bias=bias)
+        self.decoder_level2 = _stage(d2, heads[1], num_blocks[1], f, bias, ln)
+        self.up2_1 = _Resample(d2, d2 * 2)
+        self.decoder_level1 = _stage(d2, heads[0], num_blocks[0], f, bias, ln)
+        self.refinement = _stage(d2, heads[0], num_refinement_blocks, f, bias, ln)
+        self.dual_pixel_task = dual_pixel_task
+        if dual_pixel_task:
+            self.skip_conv = nn.Conv2d(d1, d2, 1, bias=bias)
+        self.output = nn.Conv2d(d2, out_channels, 3, padding=1, bias=bias)
+        self._packed = None
+        self._packed_key = None
+        self._ws = {}
+        #: tiles of one image processed per forward by the device tiler (utils.tiled_forward_device)
+        self.max_tiles_per_batch = 9
+
+    # ------------------------------------------------------------------ weights
+    def load_synthetic(self, seed=42):
+        """Fill every parameter from the deterministic generator (synth.py)."""
+        from .. import synth
+        shapes = {k: tuple(v.shape) for k, v in self.state_dict().items()}
+        self.load_state_dict(synth.synth_state_dict(shapes, seed=seed, rules=SYNTH_RULES), strict=True)
+        return self
+
+    def _param_key(self):
+        dev = None
+        ver = 0
+        for p in self.parameters():
+            dev = p.device
+            ver += p._version + (p.data_ptr() & 0xFFFF)
+        return (str(dev), ver)
+
+    def _pack(self):
+        """Packed / flattened device copies of the weights, rebuilt when parameters change."""
+        key = self._param_key()
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        pk = {}
+
+        def f32(t):
+            return None if t is None else t.detach().float().contiguous()
+
+        for name, m in self.named_modules():
+            if isinstance(m, TransformerBlock):
+                a, ff = m.attn, m.ffn
+                pk[name] = dict(
+                    qkv=_hip.pack_gemm_weight(a.qkv.weight), qkv_b=f32(a.qkv.bias),
+                    qkv_dw=f32(a.qkv_dwconv.weight.reshape(-1, 9)), qkv_dw_b=f32(a.qkv_dwconv.bias),
+                    wout=f32(a.project_out.weight.reshape(m.dim, m.dim)), wout_b=f32(a.project_out.bias),
+                    temp=f32(a.temperature.reshape(-1)),
+                    pin=_hip.pack_gemm_weight(ff.project_in.weight), pin_b=f32(ff.project_in.bias),
+                    ffn_dw=f32(ff.dwconv.weight.reshape(-1, 9)), ffn_dw_b=f32(ff.dwconv.bias),
+                    pout=_hip.pack_gemm_weight(ff.project_out.weight), pout_b=f32(ff.project_out.bias),
+                    n1w=f32(m.norm1.w), n1b=f32(m.norm1.b), n2w=f32(m.norm2.w), n2b=f32(m.norm2.b))
+        for name in ("down1_2", "down2_3", "down3_4", "up4_3", "up3_2", "up2_1"):
+            pk[name] = _hip.pack_conv3x3_weight(getattr(self, name).body[0].weight)
+        pk["patch_embed"] = _hip.pack_conv3x3_weight(self.patch_embed.proj.weight)
+        pk["patch_embed_b"] = f32(self.patch_embed.proj.bias)
+        pk["output"] = _hip.pack_conv3x3_weight(self.output.weight)
+        pk["output_b"] = f32(self.output.bias)
+        for name in ("reduce_chan_level3", "reduce_chan_level2") + (("skip_conv",) if self.dual_pixel_task else ()):
+            pk[name] = _hip.pack_gemm_weight(getattr(self, name).weight)
+            pk[name + "_b"] = f32(getattr(self, name).bias)
+        self._packed, self._packed_key = pk, key
+        return pk
+
+    # ------------------------------------------------------------------ workspace
+    def _buf(self, name, numel, device):
+        t = self._ws.get(name)
+        if t is None or t.numel() < numel or t.device != device:
+            t = torch.empty(int(numel), dtype=torch.float32, device=device)
+            self._ws[name] = t
+        return t[:numel]
+
+    def release_workspace(self):
+        self._ws.clear()
+
+    # ------------------------------------------------------------------ kernels
+    def _block(self, blk: TransformerBlock, w: dict, x: torch.Tensor):
+        """One TransformerBlock, in place on x (a [B][C][H][W] view, channel/pixel axes dense)."""
+        B, C, H, W = x.shape
+        N = H * W
+        dev = x.device
+        heads = blk.attn.num_heads
+        hid = blk.ffn.hidden
+        stats = self._buf("stats", B * 2 * N, dev)
+        big_a = self._buf("scratch_a", B * max(3 * C, 2 * hid) * N, dev)
+        big_b = self._buf("scratch_b", B * max(3 * C, hid) * N, dev)
+        qkv = big_a[:B * 3 * C * N].view(B, 3 * C, H, W)
+        qkv2 = big_b[:B * 3 * C * N].view(B, 3 * C, H, W)
+        # --- attention branch: x += project_out(softmax(q k^T) v)   (restormer.py:111-132, 147)
+        ops.ln_stats(x, stats)
+        ops.gemm1x1(w["qkv"], x, qkv, 3 * C, C, bias=w["qkv_b"], stats=stats, lnw=w["n1w"], lnb=w["n1b"],
+                    ln_mode=blk.norm1.mode)
+        ops.dwconv3x3(qkv, w["qkv_dw"], qkv2, bias=w["qkv_dw_b"])
+        _, nchunk, rec = ops.mdta_plan(B, C, heads, N)
+        part = self._buf("gram_part", B * heads * nchunk * rec, dev)
+        gsum = self._buf("gram_sum", B * heads * rec, dev)
+        mfold_n = ops.mfold_numel(C)
+        mfold = self._ws.get(("mfold", C, B))
+        if mfold is None or mfold.device != dev:
+            mfold = torch.zeros(B * mfold_n, dtype=torch.float32, device=dev)
+            self._ws[("mfold", C, B)] = mfold
+        ops.mdta_fold(qkv2, part, gsum, w["temp"], w["wout"], mfold, C, heads)
+        ops.gemm1x1(mfold, qkv2[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n)
+        # --- feed-forward branch: x += project_out(gelu(dw(h1)) * dw(h2))   (restormer.py:88-93, 148)
+        h = big_a[:B * 2 * hid * N].view(B, 2 * hid, H, W)
+        g = big_b[:B * hid * N].view(B, hid, H, W)
+        ops.ln_stats(x, stats)
+        ops.gemm1x1(w["pin"], x, h, 2 * hid, C, bias=w["pin_b"], stats=stats, lnw=w["n2w"], lnb=w["n2b"],
+                    ln_mode=blk.norm2.mode)
+        ops.dwconv3x3_gate(h, w["ffn_dw"], g, bias=w["ffn_dw_b"])
+        ops.gemm1x1(w["pout"], g, x, C, hid, res=x, bias=w["pout_b"])
+
+    @staticmethod
+    def _c3(wp, x, y, ci, co, h, w, **kw):
+        assert x.shape[2] == h and x.shape[3] == w
+        ops.conv3x3(wp, x, y, ci, co, **kw)
+
+    @staticmethod
+    def _g1(wp, x, y, m, k, **kw):
+        ops.gemm1x1(wp, x, y, m, k, **kw)
+
+    def _run_stage(self, name, pk, x):
+        for i, blk in enumerate(getattr(self, name)):
+            self._block(blk, pk[f"{name}.{i}"], x)
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, inp_img: torch.Tensor) -> torch.Tensor:
+        if not inp_img.is_cuda:
+            raise _hip.HipLibraryError("irm_amd Restormer runs on the GPU only (no CPU fallback); "
+                                       "move the model and input to 'cuda'")
+        x = inp_img.float().contiguous()
+        B, Cin, H, W = x.shape
+        if H % 8 or W % 8:
+            raise ValueError("Restormer needs H and W to be multiples of 8 (the tiler pads, utils.pad)")
+        dev = x.device
+        pk = self._pack()
+        d1, d2, d3, d4 = self.dim, self.dim * 2, self.dim * 4, self.dim * 8
+        H2, W2, H3, W3, H4, W4 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
+
+        def buf(name, ch, h, w):
+            return self._buf(name, B * ch * h * w, dev).view(B, ch, h, w)
+
+        cat1 = buf("cat1", 2 * d1, H, W)       # [up2_1 | enc1]   (restormer.py:272)
+        cat2 = buf("cat2", 2 * d2, H2, W2)     # [up3_2 | enc2]   (restormer.py:267)
+        cat3 = buf("cat3", 2 * d3, H3, W3)     # [up4_3 | enc3]   (restormer.py:262)
+        lat = buf("latent", d4, H4, W4)
+        dec3 = buf("dec3", d3, H3, W3)
+        dec2 = buf("dec2", d2, H2, W2)
+
+        e1 = cat1[:, d1:]
+        self._c3(pk["patch_embed"], x, e1, Cin, d1, H, W, bias=pk["patch_embed_b"])
+        if self.dual_pixel_task:
+            e1_in = buf("enc1_in", d1, H, W)
+            e1_in.copy_(e1)
+        self._run_stage("encoder_level1", pk, e1)
+        e2 = cat2[:, d2:]
+        self._c3(pk["down1_2"], e1, e2, d1, d1 // 2, H, W, store_mode=1)
+        self._run_stage("encoder_level2", pk, e2)
+        e3 = cat3[:, d3:]
+        self._c3(pk["down2_3"], e2, e3, d2, d2 // 2, H2, W2, store_mode=1)
+        self._run_stage("encoder_level3", pk, e3)
+        self._c3(pk["down3_4"], e3, lat, d3, d3 // 2, H3, W3, store_mode=1)
+        self._run_stage("latent", pk, lat)
+
+        self._c3(pk["up4_3"], lat, cat3[:, :d3], d4, d4 * 2, H4, W4, store_mode=2)
+        self._g1(pk["reduce_chan_level3"], cat3, dec3, d3, 2 * d3, bias=pk["reduce_chan_level3_b"])
+        self._run_stage("decoder_level3", pk, dec3)
+        self._c3(pk["up3_2"], dec3, cat2[:, :d2], d3, d3 * 2, H3, W3, store_mode=2)
+        self._g1(pk["reduce_chan_level2"], cat2, dec2, d2, 2 * d2, bias=pk["reduce_chan_level2_b"])
+        self._run_stage("decoder_level2", pk, dec2)
+        self._c3(pk["up2_1"], dec2, cat1[:, :d1], d2, d2 * 2, H2, W2, store_mode=2)
+        self._run_stage("decoder_level1", pk, cat1)
+        self._run_stage("refinement", pk, cat1)
+
+        out = torch.empty(B, self.out_channels, H, W, dtype=torch.float32, device=dev)
+        if self.dual_pixel_task:
+            self._g1(pk["skip_conv"], e1_in, cat1, d2, d1, res=cat1, bias=pk["skip_conv_b"])
+            self._c3(pk["output"], cat1, out, d2, self.out_channels, H, W, bias=pk["output_b"])
+        else:
+            self._c3(pk["output"], cat1, out, d2, self.out_channels, H, W, bias=pk["output_b"],
+                        res=x, res_mode=1)
+        return out

@@ -1,0 +1,141 @@
+/* libirm_hip.so - C ABI of the MI355X (gfx950) image-restoration hot path.
+ *
+ * The reference (leducthanhig/image-restoration-models) has no FFI of its own:
+ * its hot path is `model(input_tensor)` inside run_model_inference
+ * (src/utils.py:403-437), executed by PyTorch ATen.  These entry points are the
+ * operations a maintainer binds (ctypes stubs in INTEGRATION.md) to replace that
+ * forward and the per-tile host loop around it.  Each declaration cites the
+ * reference code it stands in for.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless stated; tensors are float32,
+ *    planar NCHW: element (b, c, n) of a tensor with batch stride `bs` (in
+ *    elements) lives at base[b*bs + c*N + n], N = H*W.  Batch strides let a
+ *    kernel read / write a channel slice of a larger (concat) buffer.
+ *  - no allocation, no host synchronisation, no global state inside: all work
+ *    is enqueued on `stream` (a hipStream_t), workspaces are passed in.
+ *  - return value: 0 = enqueued, IRM_EINVAL (-1) = rejected arguments (nothing
+ *    launched), IRM_ELAUNCH (-2) = the HIP launch failed.
+ *  - packed weights ("wp"): MFMA B-operand order produced on the host,
+ *      wp[mtile][kstep][lane] = W[16*mtile + (lane&15)][4*kstep + (lane>>4)],
+ *    zero padded, ksteps = 4*ceil(K/16) for the 1x1 GEMM and, for the 3x3
+ *    conv, wp[tap][mtile][kstep][lane] with ksteps = 2*ceil(Ci/8).
+ */
+#ifndef IRM_HIP_H
+#define IRM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* irm_stream_t; /* == hipStream_t */
+
+#define IRM_OK 0
+#define IRM_EINVAL (-1)
+#define IRM_ELAUNCH (-2)
+
+#define IRM_ACT_NONE 0
+#define IRM_ACT_RELU 1
+#define IRM_ACT_GELU 2
+#define IRM_ACT_SILU 3
+
+#define IRM_LN_NONE 0
+#define IRM_LN_WITHBIAS 1
+#define IRM_LN_BIASFREE 2
+
+/* ABI version of this header (bumped on any signature change). */
+int irm_version(void);
+
+/* Per-pixel LayerNorm statistics over channels: stats[b][0][n] = mean,
+ * stats[b][1][n] = 1/sqrt(biased_var + eps).
+ * Replaces the statistics part of BiasFree_/WithBias_LayerNorm
+ * (src/restormer/restormer.py:25-70); the normalisation itself is applied as
+ * the prologue of irm_gemm1x1_f32.  N % 4 == 0. */
+int irm_ln_stats_f32(const float* x, long x_bs, float* stats, int B, int C, int N, float eps,
+                     irm_stream_t stream);
+
+/* 1x1 convolution as a GEMM on the exact-f32 MFMA:
+ *   y[b][co][n] = act(sum_k W[co][k] * LN(x[b][k][n]) + bias[co]) (+ res[b][co][n])
+ * Replaces the bias-free 1x1 nn.Conv2d projections of Restormer
+ * (restormer.py:82 project_in, :86/:107 project_out, :105 qkv, :223/:228
+ * reduce_chan_level{3,2}, :240 skip_conv), the LayerNorm that precedes them
+ * (ln_mode, stats from irm_ln_stats_f32, lnw/lnb = LayerNorm weight/bias) and
+ * the residual add of TransformerBlock.forward (restormer.py:146-150).
+ * With w_bs != 0 each batch element has its own packed matrix (the folded
+ * attention matrix from irm_mdta_finalize_f32).
+ * ct: output-channel tiles per pass (3,4,6,8,9); ygroups: grid split of the
+ * passes (>=1).  N % 4 == 0. */
+int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long x_bs, float* y, long y_bs,
+                    const float* res, long r_bs, const float* bias, const float* stats, const float* lnw,
+                    const float* lnb, int ln_mode, int act, int B, int M, int K, int N, int ct, int ygroups,
+                    irm_stream_t stream);
+
+/* Depth-wise 3x3 convolution, zero pad 1: y[b][c] = act(dw3x3(x[b][c]; w[c]) + bias[c]).
+ * Replaces Attention.qkv_dwconv (restormer.py:106) and MaIR's conv2d+SiLU.
+ * w: [C][9] (device), bias: [C] or NULL.  W % 4 == 0. */
+int irm_dwconv3x3_f32(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs, int B,
+                      int C, int H, int W, int act, irm_stream_t stream);
+
+/* GDFN depth-wise conv + gate: x has 2*hid channels,
+ *   y[b][c] = gelu_erf(dw(x[b][c])) * dw(x[b][c + hid]),  c < hid.
+ * Replaces FeedForward.dwconv + chunk + F.gelu(x1)*x2 (restormer.py:84,89-91). */
+int irm_dwconv3x3_gate_f32(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
+                           int B, int hid, int H, int W, irm_stream_t stream);
+
+/* MDTA pass 1: per-chunk partial Gram matrices and squared norms.
+ * qkv: [B][3C][N] (after qkv_dwconv; q rows [0,C), k rows [C,2C)).
+ * part: workspace [B][heads][ceil(N/chunk)][c*c + 2c] floats, c = C/heads,
+ * c % 16 == 0, chunk % 64 == 0, N % 4 == 0.
+ * Replaces F.normalize + q @ k^T of Attention.forward (restormer.py:122-125);
+ * the normalisation is applied to the Gram matrix afterwards. */
+int irm_mdta_gram_f32(const float* qkv, long bs, float* part, int B, int C, int heads, int N, int chunk,
+                      irm_stream_t stream);
+
+/* MDTA pass 2: reduce the partials (gsum: workspace [B][heads][c*c+2c]),
+ * softmax((G_ij / (max(|q_i|,1e-12) max(|k_j|,1e-12))) * temperature[head]) and
+ * fold with project_out: mfold[b] = packed(W_out * blockdiag(A_heads)), a C x C
+ * matrix in irm_gemm1x1_f32's packed layout ([B][ceil(C/16)][4*ceil(C/16)][64];
+ * must be zero-initialised once when C % 16 != 0).  attn (optional, may be
+ * NULL) receives A as [B][heads][c][c].  wout: [C][C] row-major.
+ * Replaces restormer.py:125-131 (softmax, attn @ v, project_out) together with
+ * irm_gemm1x1_f32(mfold, v, res = block input). */
+int irm_mdta_finalize_f32(const float* part, float* gsum, const float* temperature, const float* wout,
+                          float* mfold, float* attn, int B, int C, int heads, int nchunk, irm_stream_t stream);
+
+/* Dense 3x3 convolution, stride 1, zero pad 1, implicit GEMM on the f32 MFMA:
+ *   v = conv(x)[co] + bias[co]; if relu1: v = max(v,0);
+ *   res_mode 1: v += res; res_mode 2: v = res - v; if relu2: v = max(v,0);
+ * store_mode 0: y[b][co][h][w]; 1: PixelUnshuffle(2) -> [4Co][H/2][W/2];
+ * 2: PixelShuffle(2) -> [Co/4][2H][2W].
+ * Replaces OverlapPatchEmbed / Downsample / Upsample / output (+ inp_img) of
+ * Restormer (restormer.py:156-189, 243, 281), B.conv 'CR'/'C' stacks of DnCNN
+ * incl. x - n (network_dncnn.py:40-71) and REDNet's conv / ConvTranspose2d +
+ * ReLU + skip (rednet.py:64-136).  ct in {1,2,3,4,6}. */
+int irm_conv3x3_f32(const float* wp, const float* x, long x_bs, float* y, long y_bs, const float* res, long r_bs,
+                    const float* bias, int B, int Ci, int Co, int H, int W, int relu1, int res_mode, int relu2,
+                    int store_mode, int ct, int ygroups, irm_stream_t stream);
+
+/* Tile extraction for the tiled-patch loop (src/utils.py:379-417):
+ * img [H][W][C] uint8 (is_u16=0) or uint16 -> tiles [T][C][ph][pw] float32 =
+ * img/255 (or /65535), + optional float64 noise field [th][tw][C] then clip
+ * to [0,1] (add_gaussian_noise, utils.py:29-36; the field is generated on the
+ * host with the reference's seed), then (v-mean)*inv_std (DeblurGANv2
+ * normalize; pass 0,1 to disable), reflect-padded from (th,tw) to (ph,pw)
+ * (utils.pad, utils.py:174-181).  origins: [T][2] int32 (y0,x0). */
+int irm_tile_extract(const void* img, int is_u16, const int* origins, const double* noise, float* tiles, int H,
+                     int W, int C, int th, int tw, int ph, int pw, int T, float mean, float inv_std,
+                     irm_stream_t stream);
+
+/* Gaussian-window blend + normalise + requantise (src/utils.py:427-450) with the
+ * reference's float32 operation order; pred [T][Cp][ph][pw] (first Co channels,
+ * [:th][:tw] used), window [ps][ps], out [H][W][Co] uint8/uint16.  If target
+ * and sse are given, the integer sum of squared errors vs target is added to
+ * *sse (device, 64-bit) for PSNR (utils.py:146). */
+int irm_window_blend(const float* pred, const int* origins, const float* window, void* out, int is_u16,
+                     const void* target, unsigned long long* sse, int H, int W, int Co, int Cp, int th, int tw,
+                     int ph, int pw, int ps, int T, float post_scale, float post_shift, irm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRM_HIP_H */

@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""Pin the oracle against the reference and write tests/golden/*.
+
+Runs ONLY in the build container (it imports the reference from
+/root/reference/src, CPU).  The reference never travels to the GPU box: what
+travels are the small expected-output fixtures written here, the deterministic
+weight/input generators of the product package (synth.py) and this script.
+
+What it does
+  1. imports the reference modules (Restormer, DnCNN, REDNet, src/utils.py with
+     empty stubs for the absent third-party modules cv2 / skimage / deblurganv2 /
+     mair), loads synthetic weights into them;
+  2. checks every oracle restatement in this directory against them and records
+     the max-abs differences in tests/golden/MANIFEST.json;
+  3. stores the REFERENCE outputs (not the oracle's) as golden vectors.
+
+Usage: python oracle/gen_golden.py [--only restormer|tiler|convnets|ops]
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SRC = "/root/reference/src"
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+import irm_amd  # noqa: E402
+from irm_amd import synth  # noqa: E402
+from oracle import convnets_ref, restormer_ref, tiler_ref  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+# ---------------------------------------------------------------------------
+def import_reference():
+    """sys.path import of the reference with stubs for absent third-party deps."""
+    sys.path.insert(0, REF_SRC)
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Absent:  # placeholder classes used only in isinstance() checks
+        pass
+
+    stub("cv2")
+    stub("skimage")
+    stub("skimage.metrics", peak_signal_noise_ratio=None, structural_similarity=None)
+    stub("deblurganv2", normalize=None, pad=None, postprocess=None)
+    stub("deblurganv2.models")
+    stub("deblurganv2.models.fpn_inception", FPNInception=type("FPNInception", (_Absent,), {}))
+    stub("deblurganv2.models.fpn_mobilenet", FPNMobileNet=type("FPNMobileNet", (_Absent,), {}))
+    stub("mair")
+    stub("mair.basicsr")
+    stub("mair.basicsr.archs")
+    stub("mair.basicsr.archs.mair_arch", MaIR=type("MaIR", (_Absent,), {}))
+    stub("mair.realDenoising")
+    stub("mair.realDenoising.basicsr")
+    stub("mair.realDenoising.basicsr.models")
+    stub("mair.realDenoising.basicsr.models.archs")
+    stub("mair.realDenoising.basicsr.models.archs.mairunet_arch", MaIRUNet=type("MaIRUNet", (_Absent,), {}))
+    import restormer as ref_restormer            # noqa
+    import restormer.restormer as ref_rmod       # noqa
+    import dncnn.models.network_dncnn as ref_dn  # noqa
+    import rednet.rednet as ref_red              # noqa
+    import utils as ref_utils                    # noqa
+    return types.SimpleNamespace(rmod=ref_rmod, dncnn=ref_dn, rednet=ref_red, utils=ref_utils)
+
+
+def shapes_of(module):
+    return {k: tuple(v.shape) for k, v in module.state_dict().items()}
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def maxabs(a, b) -> float:
+    return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max())
+
+
+RESTORMER_CFGS = {
+    # name: (ctor kwargs, input channels)
+    "deblur_withbias": dict(inp_channels=3, out_channels=3, LayerNorm_type="WithBias"),
+    "denoise_biasfree": dict(inp_channels=3, out_channels=3, LayerNorm_type="BiasFree"),
+    "gray_biasfree": dict(inp_channels=1, out_channels=1, LayerNorm_type="BiasFree"),
+    "dualpixel_withbias": dict(inp_channels=6, out_channels=3, LayerNorm_type="WithBias", dual_pixel_task=True),
+}
+
+
+def synth_input(name, shape, lo=0.0, hi=1.0):
+    return synth.uniform(7, name, shape, lo, hi)
+
+
+# ---------------------------------------------------------------------------
+def gen_restormer(ref, manifest):
+    from irm_amd.restormer import restormer as prod
+    out = {}
+    for name, kw in RESTORMER_CFGS.items():
+        net = ref.rmod.Restormer(**kw).eval()
+        shapes = shapes_of(net)
+        manifest.setdefault("restormer_param_shapes", {})[name] = {k: list(v) for k, v in shapes.items()}
+        sd = synth.synth_state_dict(shapes, seed=42, rules=prod.SYNTH_RULES)
+        net.load_state_dict(sd, strict=True)
+        for tag, (h, w) in {"64x64": (64, 64), "40x56": (40, 56)}.items():
+            if tag == "40x56" and name != "deblur_withbias":
+                continue
+            x = synth_input(f"restormer_in_{name}_{tag}", (1, kw["inp_channels"], h, w))
+            y_ref = net(x)
+            y_orc = restormer_ref.restormer_forward(x, sd, dual_pixel_task=kw.get("dual_pixel_task", False))
+            d = maxabs(y_ref, y_orc)
+            manifest.setdefault("oracle_vs_reference", {})[f"restormer/{name}/{tag}"] = d
+            print(f"restormer {name} {tag}: oracle-vs-reference max-abs {d:.3e}  out range "
+                  f"[{float(y_ref.min()):.3f},{float(y_ref.max()):.3f}] |y-x| mean "
+                  f"{float((y_ref - x[:, :y_ref.shape[1]]).abs().mean()) if y_ref.shape[1] <= x.shape[1] else -1:.4f}")
+            assert d <= 2e-5, d
+            out[f"{name}_{tag}"] = y_ref.numpy()
+    np.savez_compressed(os.path.join(GOLD, "restormer_forward.npz"), **out)
+
+
+def gen_ops(ref, manifest):
+    """Per-op goldens from the reference's own sub-modules."""
+    from irm_amd.restormer import restormer as prod
+    out = {}
+    R = ref.rmod
+    cases = [(48, 1, 16, 24, "WithBias"), (48, 1, 16, 24, "BiasFree"), (96, 2, 16, 16, "WithBias"),
+             (96, 1, 8, 40, "BiasFree"), (192, 4, 8, 8, "BiasFree"), (384, 8, 8, 8, "WithBias")]
+    for (c, heads, h, w, ln) in cases:
+        tag = f"c{c}_h{heads}_{h}x{w}_{ln}"
+        blk = R.TransformerBlock(dim=c, num_heads=heads, ffn_expansion_factor=2.66, bias=False,
+                                 LayerNorm_type=ln).eval()
+        sd = synth.synth_state_dict(shapes_of(blk), seed=11, rules=prod.SYNTH_RULES)
+        blk.load_state_dict(sd, strict=True)
+        x = synth_input("tb_in_" + tag, (2, c, h, w), -1.0, 1.0)
+        n1 = blk.norm1(x)
+        a = blk.attn(n1)
+        x1 = x + a
+        n2 = blk.norm2(x1)
+        f = blk.ffn(n2)
+        y = blk(x)
+        # oracle pieces
+        pre = ""
+        d = max(
+            maxabs(n1, restormer_ref.layer_norm_c(x, sd["norm1.body.weight"], sd.get("norm1.body.bias"))),
+            maxabs(a, restormer_ref.mdta(n1, sd, "attn.", heads)),
+            maxabs(f, restormer_ref.gdfn(n2, sd, "ffn.")),
+            maxabs(y, restormer_ref.transformer_block(x, sd, pre, heads)))
+        manifest.setdefault("oracle_vs_reference", {})["ops/tb_" + tag] = d
+        print(f"ops {tag}: oracle-vs-reference max-abs {d:.3e}")
+        assert d <= 2e-5
+        out["tb_" + tag + "_attn"] = a.numpy()
+        out["tb_" + tag + "_ffn"] = f.numpy()
+        out["tb_" + tag + "_out"] = y.numpy()
+    # resampling modules
+    for c, h, w in [(48, 16, 24), (96, 8, 16)]:
+        dn = R.Downsample(c).eval()
+        sd = synth.synth_state_dict(shapes_of(dn), seed=12)
+        dn.load_state_dict(sd)
+        x = synth_input(f"down_in_{c}", (2, c, h, w), -1, 1)
+        out[f"down_{c}_{h}x{w}"] = dn(x).numpy()
+        up = R.Upsample(c).eval()
+        sd = synth.synth_state_dict(shapes_of(up), seed=13)
+        up.load_state_dict(sd)
+        out[f"up_{c}_{h}x{w}"] = up(x).numpy()
+    np.savez_compressed(os.path.join(GOLD, "restormer_ops.npz"), **out)
+
+
+def gen_convnets(ref, manifest):
+    from irm_amd.dncnn import SYNTH_RULES as DN_RULES
+    from irm_amd.rednet import SYNTH_RULES as RED_RULES
+    out = {}
+    for tag, (nch, nb) in {"gray17": (1, 17), "gray20": (1, 20), "color20": (3, 20)}.items():
+        net = ref.dncnn.DnCNN(in_nc=nch, out_nc=nch, nc=64, nb=nb, act_mode="R").eval()
+        shapes = shapes_of(net)
+        manifest.setdefault("dncnn_param_shapes", {})[tag] = {k: list(v) for k, v in shapes.items()}
+        sd = synth.synth_state_dict(shapes, seed=42, rules=DN_RULES)
+        net.load_state_dict(sd, strict=True)
+        for h, w in [(32, 32), (40, 72)]:
+            x = synth_input(f"dncnn_in_{tag}_{h}x{w}", (1, nch, h, w))
+            y = net(x)
+            d = maxabs(y, convnets_ref.dncnn_forward(x, sd))
+            manifest.setdefault("oracle_vs_reference", {})[f"dncnn/{tag}/{h}x{w}"] = d
+            print(f"dncnn {tag} {h}x{w}: oracle-vs-reference {d:.3e} |y-x| {float((y-x).abs().mean()):.4f}")
+            assert d <= 2e-5
+            out[f"dncnn_{tag}_{h}x{w}"] = y.numpy()
+    net = ref.rednet.REDNet().eval()
+    shapes = shapes_of(net)
+    manifest["rednet_param_shapes"] = {k: list(v) for k, v in shapes.items()}
+    sd = synth.synth_state_dict(shapes, seed=42, rules=RED_RULES)
+    net.load_state_dict(sd, strict=True)
+    for h, w in [(32, 32), (24, 40)]:
+        x = synth_input(f"rednet_in_{h}x{w}", (1, 1, h, w))
+        y = net(x)
+        d = maxabs(y, convnets_ref.rednet_forward(x, sd))
+        manifest.setdefault("oracle_vs_reference", {})[f"rednet/{h}x{w}"] = d
+        print(f"rednet {h}x{w}: oracle-vs-reference {d:.3e} |y-x| {float((y-x).abs().mean()):.4f}")
+        assert d <= 2e-5
+        out[f"rednet_{h}x{w}"] = y.numpy()
+    np.savez_compressed(os.path.join(GOLD, "convnets_forward.npz"), **out)
+
+
+def gen_tiler(ref, manifest):
+    """The reference's run_model_inference (src/utils.py:353-454) itself, on CPU."""
+    from irm_amd import configs as prod_cfg
+    from irm_amd.dncnn import SYNTH_RULES as DN_RULES
+    from irm_amd.restormer import restormer as prod
+    U = ref.utils
+    out = {}
+    # (5) tile index lists for every PATCH_CONFIG entry x sizes
+    idx = {}
+    flat = []
+    for k, v in prod_cfg.PATCH_CONFIG.items():
+        for i, e in enumerate(v if isinstance(v, list) else [v]):
+            flat.append((f"{k}[{i}]", e["patch_size"], e["patch_overlap"]))
+    for name, ps0, ov in flat:
+        for (h, w) in [(256, 256), (512, 512), (720, 1280), (481, 321), (300, 420)]:
+            ps = min(ps0, max(h, w))
+            stride = max(ps - ov, 1)
+            ref_h = list(range(0, h - ps, stride)) + [max(h - ps, 0)]
+            ref_w = list(range(0, w - ps, stride)) + [max(w - ps, 0)]
+            assert ref_h == tiler_ref.tile_origins(h, ps, ov) and ref_w == tiler_ref.tile_origins(w, ps, ov)
+            idx[f"{name}|{h}x{w}"] = [ps, ref_h, ref_w]
+    manifest["tile_origins"] = idx
+    # windows / pad / noise
+    for n in (64, 128, 200):
+        wref = U.get_gaussian_weights(n, n, 3)
+        assert np.array_equal(wref, tiler_ref.gaussian_window(n, n, 3))
+    out["window_64"] = U.get_gaussian_weights(64, 64, 1)[:, :, 0]
+    t = synth_input("padcheck", (1, 3, 37, 50))
+    assert torch.equal(U.pad(t), tiler_ref.reflect_pad8(t))
+    tl = synth_input("noisecheck", (40, 48, 3)).numpy()
+    assert np.array_equal(U.add_gaussian_noise(tl.copy(), 25), tiler_ref.degrade(tl, 25))
+    out["noise_40x48x3_s25"] = U.add_gaussian_noise(tl.copy(), 25)
+
+    # (3a) DnCNN through the tiler on a 150x210 gray image with a shrunk patch config + noise
+    net = ref.dncnn.DnCNN(in_nc=1, out_nc=1, nc=64, nb=17, act_mode="R").eval()
+    sd = synth.synth_state_dict(shapes_of(net), seed=42, rules=DN_RULES)
+    net.load_state_dict(sd)
+    img, _ = synth.synth_image_pair(1, 150, 210, 1, seed_base=3000, blur=0)
+    for tag, kw in {"dncnn_tiled": dict(patch_size=64, patch_overlap=16),
+                    "dncnn_tiled_noise": dict(patch_size=64, patch_overlap=16, need_degradation=True, noise_level=25),
+                    "dncnn_whole": dict(patch_size=None)}.items():
+        pred_ref, _ = U.run_model_inference(net, img, torch.device("cpu"), **kw)
+        pred_orc = tiler_ref.tiled_inference(lambda t: convnets_ref.dncnn_forward(t, sd), img, **kw)
+        nd = int((pred_ref.astype(int) != pred_orc.astype(int)).sum())
+        manifest.setdefault("oracle_vs_reference", {})[f"tiler/{tag}/u8_mismatches"] = nd
+        print(f"tiler {tag}: u8 mismatches oracle-vs-reference {nd} of {pred_ref.size}")
+        assert nd == 0
+        out[tag] = pred_ref
+    # (3b) Restormer through the tiler incl. utils.pad: 100x136 image, patch 64 / overlap 16 -> edge tiles
+    rnet = ref.rmod.Restormer(LayerNorm_type="WithBias").eval()
+    rsd = synth.synth_state_dict(shapes_of(rnet), seed=42, rules=prod.SYNTH_RULES)
+    rnet.load_state_dict(rsd)
+    img3, tgt3 = synth.synth_image_pair(2, 100, 136, 3, seed_base=1000, blur=7)
+    tiles_ref = []
+    orig_call = rnet.forward
+
+    def spy(x):
+        y = orig_call(x)
+        tiles_ref.append(y.numpy().copy())
+        return y
+    rnet.forward = spy
+    pred_ref, _ = U.run_model_inference(rnet, img3, torch.device("cpu"), pad=U.pad, patch_size=64, patch_overlap=16)
+    rnet.forward = orig_call
+    pred_orc = tiler_ref.tiled_inference(lambda t: restormer_ref.restormer_forward(t, rsd), img3,
+                                         pad=tiler_ref.reflect_pad8, patch_size=64, patch_overlap=16)
+    nd = int((pred_ref.astype(int) != pred_orc.astype(int)).sum())
+    manifest["oracle_vs_reference"]["tiler/restormer_tiled/u8_mismatches"] = nd
+    print(f"tiler restormer_tiled: u8 mismatches {nd} of {pred_ref.size}; psnr vs target "
+          f"{tiler_ref.psnr(tgt3, pred_ref):.4f}")
+    assert nd <= 2
+    out["restormer_tiled"] = pred_ref
+    out["restormer_tiled_tile0"] = tiles_ref[0]
+    manifest["restormer_tiled_psnr"] = tiler_ref.psnr(tgt3, pred_ref)
+    np.savez_compressed(os.path.join(GOLD, "tiler.npz"), **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    mpath = os.path.join(GOLD, "MANIFEST.json")
+    manifest = json.load(open(mpath)) if os.path.exists(mpath) else {}
+    ref = import_reference()
+    steps = {"ops": gen_ops, "restormer": gen_restormer, "convnets": gen_convnets, "tiler": gen_tiler}
+    for k, fn in steps.items():
+        if args.only in (None, k):
+            fn(ref, manifest)
+    manifest["generated_by"] = "oracle/gen_golden.py (reference imported from /root/reference/src, torch CPU fp32)"
+    manifest["torch"] = torch.__version__
+    json.dump(manifest, open(mpath, "w"), indent=1, sort_keys=True)
+    print("wrote", mpath)
+
+
+if __name__ == "__main__":
+    main()
