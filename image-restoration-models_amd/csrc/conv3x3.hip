@@ -38,6 +38,7 @@ struct ConvArgs {
     int relu2;                    // relu after the residual
     int store_mode;               // 0 NCHW, 1 PixelUnshuffle(2), 2 PixelShuffle(2)
     int tiles_x;
+    int vec;                      // 16-byte / 8-byte store fast paths are legal
 };
 
 template <int CT>
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
                     }
                     if (a.store_mode == 0) {
                         const long off = (long)co * plane + (long)y * a.W + x;
-                        if ((a.W & 3) == 0) {
+                        if (a.vec) {
                             if (a.res_mode) {
                                 const float4 rr = *reinterpret_cast<const float4*>(R + off);
                                 const float rv[4] = {rr.x, rr.y, rr.z, rr.w};
@@ -176,13 +177,19 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
                             }
                         }
                     } else if (a.store_mode == 1) {
-                        // PixelUnshuffle(2): out[co*4 + (y&1)*2 + (x&1)][y/2][x/2]; H, W even, x % 4 == 0
+                        // PixelUnshuffle(2): out[co*4 + (y&1)*2 + (x&1)][y/2][x/2]; H, W even
                         const int oh = a.H >> 1, ow = a.W >> 1;
                         const long op = (long)oh * ow;
                         const int oc = co * 4 + (y & 1) * 2;
                         const long o = (long)(y >> 1) * ow + (x >> 1);
-                        *reinterpret_cast<float2*>(Y + (long)oc * op + o) = make_float2(v[0], v[2]);
-                        *reinterpret_cast<float2*>(Y + (long)(oc + 1) * op + o) = make_float2(v[1], v[3]);
+                        if (a.vec) {
+                            *reinterpret_cast<float2*>(Y + (long)oc * op + o) = make_float2(v[0], v[2]);
+                            *reinterpret_cast<float2*>(Y + (long)(oc + 1) * op + o) = make_float2(v[1], v[3]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (x + e < a.W) Y[(long)(oc + (e & 1)) * op + o + (e >> 1)] = v[e];
+                        }
                     } else {
                         // PixelShuffle(2): out[co/4][2y + ((co>>1)&1)][2x + (co&1)]
                         const int ow = a.W * 2;
@@ -190,7 +197,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
                         const int oc = co >> 2, i = (co >> 1) & 1, jx = co & 1;
                         float* o = Y + (long)oc * op + (long)(2 * y + i) * ow + 2 * x + jx;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[2 * e] = v[e];
+                        for (int e = 0; e < 4; ++e)
+                            if (x + e < a.W) o[2 * e] = v[e];
                     }
                 }
             }
@@ -213,7 +221,7 @@ extern "C" int irm_conv3x3_f32(const float* wp, const float* x, long x_bs, float
     if (!wp || !x || !y || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return IRM_EINVAL;
     if (res_mode < 0 || res_mode > 2 || (res_mode && !res) || store_mode < 0 || store_mode > 2) return IRM_EINVAL;
     if (store_mode != 0 && res_mode != 0) return IRM_EINVAL;
-    if (store_mode == 1 && ((H & 1) || (W & 3))) return IRM_EINVAL;
+    if (store_mode == 1 && ((H & 1) || (W & 1))) return IRM_EINVAL;
     if (store_mode == 2 && (Co & 3)) return IRM_EINVAL;
     if (B > 65535) return IRM_EINVAL;
     ConvArgs a;
@@ -222,6 +230,7 @@ extern "C" int irm_conv3x3_f32(const float* wp, const float* x, long x_bs, float
     a.mtiles = (Co + 15) / 16; a.ksteps = 2 * ((Ci + 7) / 8);
     a.relu1 = relu1; a.res_mode = res_mode; a.relu2 = relu2; a.store_mode = store_mode;
     a.tiles_x = (W + CV_TW - 1) / CV_TW;
+    a.vec = !(W & 3) && !(y_bs & 3) && !(r_bs & 3) && irm_aligned16(y) && irm_aligned16(res);
     if (ct <= 0) return IRM_EINVAL;
     const int nchunks = (a.mtiles + ct - 1) / ct;
     if (ygroups <= 0) ygroups = 1;

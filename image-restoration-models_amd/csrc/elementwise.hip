@@ -7,15 +7,16 @@
 // mean and rstd = 1/sqrt(biased var + eps).  One thread owns 4 consecutive
 // pixels (16-byte loads, a wave reads 1 KiB per channel row) and runs Welford
 // over the C rows, so x is read exactly once.
+template <bool VEC>
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, long x_bs,
                                                        float* __restrict__ stats, int C, int N, float eps) {
     const int b = blockIdx.y;
     const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (n >= N) return;
-    const float* p = x + (long)b * x_bs + n;
+    const float* p = x + (long)b * x_bs;
     float4 mean = make_float4(0.f, 0.f, 0.f, 0.f), m2 = mean;
     for (int c = 0; c < C; ++c) {
-        const float4 v = *reinterpret_cast<const float4*>(p + (long)c * N);
+        const float4 v = irm_ld4<VEC>(p + (long)c * N, n, N);
         const float rc = 1.0f / (float)(c + 1);
         float d;
         d = v.x - mean.x; mean.x += d * rc; m2.x += d * (v.x - mean.x);
@@ -30,15 +31,17 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
     rstd.z = 1.0f / sqrtf(m2.z * inv + eps);
     rstd.w = 1.0f / sqrtf(m2.w * inv + eps);
     float* s = stats + (long)b * 2 * N;
-    *reinterpret_cast<float4*>(s + n) = mean;
-    *reinterpret_cast<float4*>(s + N + n) = rstd;
+    irm_st4<VEC>(s, n, N, mean);
+    irm_st4<VEC>(s + N, n, N, rstd);
 }
 
 extern "C" int irm_ln_stats_f32(const float* x, long x_bs, float* stats, int B, int C, int N, float eps,
                                 hipStream_t stream) {
-    if (!x || !stats || B <= 0 || C <= 0 || N <= 0 || (N & 3) || (x_bs & 3) || B > 65535) return IRM_EINVAL;
-    dim3 grid((N / 4 + 255) / 256, B);
-    hipLaunchKernelGGL(ln_stats_kernel, grid, dim3(256), 0, stream, x, x_bs, stats, C, N, eps);
+    if (!x || !stats || B <= 0 || C <= 0 || N <= 0 || B > 65535) return IRM_EINVAL;
+    dim3 grid(((N + 3) / 4 + 255) / 256, B);
+    const bool vec = !(N & 3) && !(x_bs & 3) && irm_aligned16(x) && irm_aligned16(stats);
+    if (vec) hipLaunchKernelGGL(ln_stats_kernel<true>, grid, dim3(256), 0, stream, x, x_bs, stats, C, N, eps);
+    else hipLaunchKernelGGL(ln_stats_kernel<false>, grid, dim3(256), 0, stream, x, x_bs, stats, C, N, eps);
     return irm_launch_status();
 }
 
@@ -57,17 +60,18 @@ struct DwArgs {
     int H, W, act;
 };
 
+template <bool VEC>
 __device__ __forceinline__ void dw_load_row(const float* plane, int row, int H, int W, int col, float (&r)[6]) {
     if (row < 0 || row >= H) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) r[i] = 0.0f;
         return;
     }
-    const float* p = plane + (long)row * W + col;
-    const float4 v = *reinterpret_cast<const float4*>(p);
-    r[0] = col > 0 ? p[-1] : 0.0f;
+    const float* p = plane + (long)row * W;
+    const float4 v = irm_ld4<VEC>(p, col, W);
+    r[0] = col > 0 ? p[col - 1] : 0.0f;
     r[1] = v.x; r[2] = v.y; r[3] = v.z; r[4] = v.w;
-    r[5] = col + 4 < W ? p[4] : 0.0f;
+    r[5] = col + 4 < W ? p[col + 4] : 0.0f;
 }
 
 __device__ __forceinline__ float4 dw_apply(const float (&k)[9], const float (&r0)[6], const float (&r1)[6],
@@ -84,9 +88,9 @@ __device__ __forceinline__ float4 dw_apply(const float (&k)[9], const float (&r0
     return make_float4(o[0], o[1], o[2], o[3]);
 }
 
-template <bool GATE, int RS>
+template <bool GATE, int RS, bool VEC>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs a) {
-    const int cgs = a.W >> 2;
+    const int cgs = (a.W + 3) >> 2;
     const int strips = (a.H + RS - 1) / RS;
     const long total = (long)a.C * strips * cgs;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -118,20 +122,20 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs a) {
     float* yo = a.y + (long)b * a.y_bs + (long)c * plane;
 
     float a0[6], a1[6], a2[6], b0[6], b1[6], b2[6];
-    dw_load_row(xa, y0 - 1, a.H, a.W, col, a0);
-    dw_load_row(xa, y0, a.H, a.W, col, a1);
+    dw_load_row<VEC>(xa, y0 - 1, a.H, a.W, col, a0);
+    dw_load_row<VEC>(xa, y0, a.H, a.W, col, a1);
     if (GATE) {
-        dw_load_row(xb, y0 - 1, a.H, a.W, col, b0);
-        dw_load_row(xb, y0, a.H, a.W, col, b1);
+        dw_load_row<VEC>(xb, y0 - 1, a.H, a.W, col, b0);
+        dw_load_row<VEC>(xb, y0, a.H, a.W, col, b1);
     }
 #pragma unroll
     for (int r = 0; r < RS; ++r) {
         const int y = y0 + r;
         if (y >= a.H) break;
-        dw_load_row(xa, y + 1, a.H, a.W, col, a2);
+        dw_load_row<VEC>(xa, y + 1, a.H, a.W, col, a2);
         float4 o = dw_apply(ka, a0, a1, a2, ba);
         if (GATE) {
-            dw_load_row(xb, y + 1, a.H, a.W, col, b2);
+            dw_load_row<VEC>(xb, y + 1, a.H, a.W, col, b2);
             const float4 g = dw_apply(kb, b0, b1, b2, bb);
             o.x = irm_gelu(o.x) * g.x; o.y = irm_gelu(o.y) * g.y;
             o.z = irm_gelu(o.z) * g.z; o.w = irm_gelu(o.w) * g.w;
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs a) {
             o.x = irm_act(o.x, a.act); o.y = irm_act(o.y, a.act);
             o.z = irm_act(o.z, a.act); o.w = irm_act(o.w, a.act);
         }
-        *reinterpret_cast<float4*>(yo + (long)y * a.W + col) = o;
+        irm_st4<VEC>(yo + (long)y * a.W, col, a.W, o);
 #pragma unroll
         for (int i = 0; i < 6; ++i) { a0[i] = a1[i]; a1[i] = a2[i]; }
     }
@@ -149,19 +153,21 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs a) {
 
 static int dw_launch(bool gate, const DwArgs& a, int B, hipStream_t stream) {
     constexpr int RS = 8;
-    const long total = (long)a.C * ((a.H + RS - 1) / RS) * (a.W >> 2);
+    const long total = (long)a.C * ((a.H + RS - 1) / RS) * ((a.W + 3) >> 2);
     const long blocks = (total + 255) / 256;
     if (blocks > 2147483647L || B > 65535) return IRM_EINVAL;
     dim3 grid((unsigned)blocks, B);
-    if (gate) hipLaunchKernelGGL((dwconv3x3_kernel<true, RS>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((dwconv3x3_kernel<false, RS>), grid, dim3(256), 0, stream, a);
+    const bool vec = !(a.W & 3) && !(a.x_bs & 3) && !(a.y_bs & 3) && irm_aligned16(a.x) && irm_aligned16(a.y);
+    if (gate && vec) hipLaunchKernelGGL((dwconv3x3_kernel<true, RS, true>), grid, dim3(256), 0, stream, a);
+    else if (gate) hipLaunchKernelGGL((dwconv3x3_kernel<true, RS, false>), grid, dim3(256), 0, stream, a);
+    else if (vec) hipLaunchKernelGGL((dwconv3x3_kernel<false, RS, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((dwconv3x3_kernel<false, RS, false>), grid, dim3(256), 0, stream, a);
     return irm_launch_status();
 }
 
 extern "C" int irm_dwconv3x3_f32(const float* x, long x_bs, const float* w, const float* bias, float* y,
                                  long y_bs, int B, int C, int H, int W, int act, hipStream_t stream) {
-    if (!x || !w || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3) || (x_bs & 3) || (y_bs & 3))
-        return IRM_EINVAL;
+    if (!x || !w || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return IRM_EINVAL;
     if (act < 0 || act > 3) return IRM_EINVAL;
     DwArgs a{x, x_bs, w, bias, y, y_bs, C, H, W, act};
     return dw_launch(false, a, B, stream);
@@ -169,8 +175,7 @@ extern "C" int irm_dwconv3x3_f32(const float* x, long x_bs, const float* w, cons
 
 extern "C" int irm_dwconv3x3_gate_f32(const float* x, long x_bs, const float* w, const float* bias, float* y,
                                       long y_bs, int B, int hid, int H, int W, hipStream_t stream) {
-    if (!x || !w || !y || B <= 0 || hid <= 0 || H <= 0 || W <= 0 || (W & 3) || (x_bs & 3) || (y_bs & 3))
-        return IRM_EINVAL;
+    if (!x || !w || !y || B <= 0 || hid <= 0 || H <= 0 || W <= 0) return IRM_EINVAL;
     DwArgs a{x, x_bs, w, bias, y, y_bs, hid, H, W, IRM_ACT_NONE};
     return dw_launch(true, a, B, stream);
 }

@@ -35,7 +35,7 @@ struct GemmArgs {
     int ln_mode, act;
 };
 
-template <int PT, int CT>
+template <int PT, int CT, bool VEC>
 __global__ __launch_bounds__(256) void gemm_pw_kernel(GemmArgs a) {
     constexpr int BN = 64 * PT;      // pixels per workgroup
     constexpr int BNP = BN + 16;     // row stride: rows k and k+1 land on disjoint bank halves
@@ -60,13 +60,13 @@ __global__ __launch_bounds__(256) void gemm_pw_kernel(GemmArgs a) {
     const int r0 = tid / XV;
     constexpr int RSTEP = 256 / XV;
     const int ncol = n0 + c4 * 4;
-    const bool col_ok = ncol < a.N;          // N % 4 == 0 (checked on the host)
+    const bool col_ok = ncol < a.N;
 
     float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(1.f, 1.f, 1.f, 1.f);
     if (a.ln_mode != IRM_LN_NONE && col_ok) {
         const float* st = a.stats + (long)b * 2 * a.N;
-        mu = *reinterpret_cast<const float4*>(st + ncol);
-        rs = *reinterpret_cast<const float4*>(st + a.N + ncol);
+        mu = irm_ld4<VEC>(st, ncol, a.N);
+        rs = irm_ld4<VEC>(st + a.N, ncol, a.N);
     }
 
     const int nstages = a.ksteps / 4;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void gemm_pw_kernel(GemmArgs a) {
             const int k = s * BK + r0 + j * RSTEP;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (col_ok && k < a.K) {
-                v = *reinterpret_cast<const float4*>(X + (long)k * a.N + ncol);
+                v = irm_ld4<VEC>(X + (long)k * a.N, ncol, a.N);
                 if (a.ln_mode == IRM_LN_WITHBIAS) {
                     const float w = a.lnw[k], bb = a.lnb[k];
                     v.x = (v.x - mu.x) * rs.x * w + bb;
@@ -177,12 +177,12 @@ __global__ __launch_bounds__(256) void gemm_pw_kernel(GemmArgs a) {
                             v.x = irm_act(v.x, a.act); v.y = irm_act(v.y, a.act);
                             v.z = irm_act(v.z, a.act); v.w = irm_act(v.w, a.act);
                         }
-                        const long off = (long)co * a.N + pix;
+                        const long off = (long)co * a.N;
                         if (R) {
-                            const float4 r = *reinterpret_cast<const float4*>(R + off);
+                            const float4 r = irm_ld4<VEC>(R + off, pix, a.N);
                             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                         }
-                        *reinterpret_cast<float4*>(Y + off) = v;
+                        irm_st4<VEC>(Y + off, pix, a.N, v);
                     }
                 }
             }
@@ -191,10 +191,11 @@ __global__ __launch_bounds__(256) void gemm_pw_kernel(GemmArgs a) {
 }
 
 template <int PT, int CT>
-static int launch_gemm(const GemmArgs& a, int B, int ygroups, hipStream_t stream) {
+static int launch_gemm(const GemmArgs& a, int B, int ygroups, bool vec, hipStream_t stream) {
     constexpr int BN = 64 * PT;
     dim3 grid((a.N + BN - 1) / BN, ygroups, B);
-    hipLaunchKernelGGL((gemm_pw_kernel<PT, CT>), grid, dim3(256), 0, stream, a);
+    if (vec) hipLaunchKernelGGL((gemm_pw_kernel<PT, CT, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_pw_kernel<PT, CT, false>), grid, dim3(256), 0, stream, a);
     return irm_launch_status();
 }
 
@@ -204,10 +205,13 @@ extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long 
                                const float* res, long r_bs, const float* bias, const float* stats,
                                const float* lnw, const float* lnb, int ln_mode, int act, int B, int M, int K,
                                int N, int ct, int ygroups, hipStream_t stream) {
-    if (!wp || !x || !y || B <= 0 || M <= 0 || K <= 0 || N <= 0 || (N & 3)) return IRM_EINVAL;
+    if (!wp || !x || !y || B <= 0 || M <= 0 || K <= 0 || N <= 0) return IRM_EINVAL;
     if (ln_mode != IRM_LN_NONE && (!stats || !lnw || (ln_mode == IRM_LN_WITHBIAS && !lnb))) return IRM_EINVAL;
     if (ln_mode < 0 || ln_mode > 2 || act < 0 || act > 3) return IRM_EINVAL;
-    if ((x_bs & 3) || (y_bs & 3) || (r_bs & 3) || (w_bs & 3)) return IRM_EINVAL;
+    if ((w_bs & 3) || !irm_aligned16(wp)) return IRM_EINVAL;
+    // 16-byte fast path needs every row of every operand 16-byte aligned
+    const bool vec = !(N & 3) && !(x_bs & 3) && !(y_bs & 3) && !(r_bs & 3) && irm_aligned16(x) &&
+                     irm_aligned16(y) && irm_aligned16(res) && irm_aligned16(stats);
     GemmArgs a;
     a.Wp = wp; a.w_bs = w_bs; a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.R = res; a.r_bs = r_bs;
     a.bias = bias; a.stats = stats; a.lnw = lnw; a.lnb = lnb;
@@ -218,11 +222,11 @@ extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long 
     if (ygroups > nchunks) ygroups = nchunks;
     if (B > 65535 || ygroups > 65535) return IRM_EINVAL;
     switch (ct) {
-        case 3: return launch_gemm<2, 3>(a, B, ygroups, stream);
-        case 4: return launch_gemm<2, 4>(a, B, ygroups, stream);
-        case 6: return launch_gemm<2, 6>(a, B, ygroups, stream);
-        case 8: return launch_gemm<2, 8>(a, B, ygroups, stream);
-        case 9: return launch_gemm<2, 9>(a, B, ygroups, stream);
+        case 3: return launch_gemm<2, 3>(a, B, ygroups, vec, stream);
+        case 4: return launch_gemm<2, 4>(a, B, ygroups, vec, stream);
+        case 6: return launch_gemm<2, 6>(a, B, ygroups, vec, stream);
+        case 8: return launch_gemm<2, 8>(a, B, ygroups, vec, stream);
+        case 9: return launch_gemm<2, 9>(a, B, ygroups, vec, stream);
         default: return IRM_EINVAL;
     }
 }

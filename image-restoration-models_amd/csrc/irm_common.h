@@ -41,3 +41,25 @@ __device__ __forceinline__ float irm_act(float v, int act) {
 __device__ __forceinline__ f32x4 irm_mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+// 4 consecutive floats at row[n..n+3]; VEC: one 16-byte access (row + n 16-byte aligned, n + 3 < N
+// whenever n < N), else guarded scalars (elements at or beyond N read as 0 / are not written).
+template <bool VEC>
+__device__ __forceinline__ float4 irm_ld4(const float* row, int n, int N) {
+    if (VEC) return *reinterpret_cast<const float4*>(row + n);
+    float4 v;
+    v.x = n < N ? row[n] : 0.0f;
+    v.y = n + 1 < N ? row[n + 1] : 0.0f;
+    v.z = n + 2 < N ? row[n + 2] : 0.0f;
+    v.w = n + 3 < N ? row[n + 3] : 0.0f;
+    return v;
+}
+template <bool VEC>
+__device__ __forceinline__ void irm_st4(float* row, int n, int N, float4 v) {
+    if (VEC) { *reinterpret_cast<float4*>(row + n) = v; return; }
+    if (n < N) row[n] = v.x;
+    if (n + 1 < N) row[n + 1] = v.y;
+    if (n + 2 < N) row[n + 2] = v.z;
+    if (n + 3 < N) row[n + 3] = v.w;
+}
+static inline bool irm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -29,7 +29,7 @@ struct GramArgs {
     int C, heads, N, chunk, nchunk;
 };
 
-template <int SB>
+template <int SB, bool VEC>
 __global__ __launch_bounds__(256) void mdta_gram_kernel(GramArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -39,10 +39,8 @@ __global__ __launch_bounds__(256) void mdta_gram_kernel(GramArgs a) {
     // unit id: sub-block fastest so that waves sharing q/k rows sit in one workgroup
     const long unit = (long)blockIdx.x * 4 + wave;
     const long units_per_bh = (long)nsub * a.nchunk;
-    const long total = (long)gridDim.y * a.heads * units_per_bh;
     const int b = blockIdx.y;
     if (unit >= a.heads * units_per_bh) return;
-    (void)total;
     const int head = (int)(unit / units_per_bh);
     const long rem = unit % units_per_bh;
     const int chunk_id = (int)(rem / nsub);
@@ -69,13 +67,11 @@ __global__ __launch_bounds__(256) void mdta_gram_kernel(GramArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = slab + 16 * j + 4 * g;
-            const bool ok = n < nend;             // N, chunk are multiples of 4
+            const bool ok = n < nend;             // chunk starts are multiples of 64
 #pragma unroll
             for (int i = 0; i < SB; ++i) {
-                qa[i][j] = ok ? *reinterpret_cast<const float4*>(q + (long)i * 16 * a.N + n)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-                ka[i][j] = ok ? *reinterpret_cast<const float4*>(k + (long)i * 16 * a.N + n)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                qa[i][j] = ok ? irm_ld4<VEC>(q + (long)i * 16 * a.N, n, nend) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ka[i][j] = ok ? irm_ld4<VEC>(k + (long)i * 16 * a.N, n, nend) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
@@ -129,7 +125,7 @@ __global__ __launch_bounds__(256) void mdta_gram_kernel(GramArgs a) {
 extern "C" int irm_mdta_gram_f32(const float* qkv, long bs, float* part, int B, int C, int heads, int N,
                                  int chunk, hipStream_t stream) {
     if (!qkv || !part || B <= 0 || C <= 0 || heads <= 0 || N <= 0 || chunk <= 0) return IRM_EINVAL;
-    if (C % heads || (N & 3) || (chunk & 63) || (bs & 3) || B > 65535) return IRM_EINVAL;
+    if (C % heads || (chunk & 63) || B > 65535) return IRM_EINVAL;
     const int c = C / heads;
     if (c % 16) return IRM_EINVAL;
     GramArgs a{qkv, bs, part, C, heads, N, chunk, (N + chunk - 1) / chunk};
@@ -137,9 +133,16 @@ extern "C" int irm_mdta_gram_f32(const float* qkv, long bs, float* part, int B, 
     const int nsb = c / (16 * sb);
     const long units = (long)heads * nsb * nsb * a.nchunk;
     dim3 grid((unsigned)((units + 3) / 4), B);
-    if (sb == 3) hipLaunchKernelGGL((mdta_gram_kernel<3>), grid, dim3(256), 0, stream, a);
-    else if (sb == 2) hipLaunchKernelGGL((mdta_gram_kernel<2>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((mdta_gram_kernel<1>), grid, dim3(256), 0, stream, a);
+    const bool vec = !(N & 3) && !(bs & 3) && irm_aligned16(qkv);
+    if (vec) {
+        if (sb == 3) hipLaunchKernelGGL((mdta_gram_kernel<3, true>), grid, dim3(256), 0, stream, a);
+        else if (sb == 2) hipLaunchKernelGGL((mdta_gram_kernel<2, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((mdta_gram_kernel<1, true>), grid, dim3(256), 0, stream, a);
+    } else {
+        if (sb == 3) hipLaunchKernelGGL((mdta_gram_kernel<3, false>), grid, dim3(256), 0, stream, a);
+        else if (sb == 2) hipLaunchKernelGGL((mdta_gram_kernel<2, false>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((mdta_gram_kernel<1, false>), grid, dim3(256), 0, stream, a);
+    }
     return irm_launch_status();
 }
 

@@ -1,0 +1,226 @@
+"""CPU-only tests (python -m pytest tests -m "not gpu"): the oracle against the
+committed golden vectors (reference outputs), the host-side logic of the
+product package, and the C-ABI library (loads, exports every declared symbol -
+no compute calls without a GPU)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from irm_amd import _hip, configs, dncnn, rednet, restormer, synth, utils
+from oracle import convnets_ref, restormer_ref, tiler_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def gin(name, shape, lo=0.0, hi=1.0):
+    return synth.uniform(7, name, shape, lo, hi)
+
+
+# --------------------------------------------------------------------------- oracle vs golden
+def test_oracle_was_pinned_to_reference(manifest):
+    """oracle/gen_golden.py recorded oracle-vs-imported-reference differences: all must be ~0."""
+    diffs = manifest["oracle_vs_reference"]
+    assert len(diffs) >= 20
+    assert max(diffs.values()) <= 2e-5
+
+
+@pytest.mark.parametrize("cfg,kw", [("deblur_withbias", dict(LayerNorm_type="WithBias")),
+                                    ("gray_biasfree", dict(inp_channels=1, out_channels=1, LayerNorm_type="BiasFree"))])
+def test_oracle_restormer_vs_golden(golden, manifest, cfg, kw):
+    shapes = {k: tuple(v) for k, v in manifest["restormer_param_shapes"][cfg].items()}
+    sd = synth.synth_state_dict(shapes, seed=42, rules=restormer.restormer.SYNTH_RULES)
+    x = gin(f"restormer_in_{cfg}_64x64", (1, kw.get("inp_channels", 3), 64, 64))
+    with torch.no_grad():
+        y = restormer_ref.restormer_forward(x, sd).numpy()
+    assert np.abs(y - golden("restormer_forward")[f"{cfg}_64x64"]).max() <= 1e-5
+
+
+def test_oracle_convnets_vs_golden(golden, manifest):
+    shapes = {k: tuple(v) for k, v in manifest["dncnn_param_shapes"]["gray17"].items()}
+    sd = synth.synth_state_dict(shapes, seed=42, rules=dncnn.SYNTH_RULES)
+    x = gin("dncnn_in_gray17_32x32", (1, 1, 32, 32))
+    with torch.no_grad():
+        y = convnets_ref.dncnn_forward(x, sd).numpy()
+    assert np.abs(y - golden("convnets_forward")["dncnn_gray17_32x32"]).max() <= 1e-5
+    shapes = {k: tuple(v) for k, v in manifest["rednet_param_shapes"].items()}
+    sd = synth.synth_state_dict(shapes, seed=42, rules=rednet.SYNTH_RULES)
+    x = gin("rednet_in_24x40", (1, 1, 24, 40))
+    with torch.no_grad():
+        y = convnets_ref.rednet_forward(x, sd).numpy()
+    assert np.abs(y - golden("convnets_forward")["rednet_24x40"]).max() <= 1e-5
+
+
+def test_oracle_tiler_vs_golden(golden, manifest):
+    """numpy tiler restatement + DnCNN oracle == the reference's run_model_inference output (u8 exact)."""
+    shapes = {k: tuple(v) for k, v in manifest["dncnn_param_shapes"]["gray17"].items()}
+    sd = synth.synth_state_dict(shapes, seed=42, rules=dncnn.SYNTH_RULES)
+    img, _ = synth.synth_image_pair(1, 150, 210, 1, seed_base=3000, blur=0)
+    pred = tiler_ref.tiled_inference(lambda t: convnets_ref.dncnn_forward(t, sd), img, patch_size=64,
+                                     patch_overlap=16, need_degradation=True, noise_level=25)
+    assert np.array_equal(pred, golden("tiler")["dncnn_tiled_noise"])
+    assert np.array_equal(tiler_ref.gaussian_window(64, 64, 1)[:, :, 0], golden("tiler")["window_64"])
+    tl = gin("noisecheck", (40, 48, 3)).numpy()
+    assert np.array_equal(tiler_ref.degrade(tl, 25), golden("tiler")["noise_40x48x3_s25"])
+
+
+# --------------------------------------------------------------------------- host logic
+def test_tile_origins_match_reference(manifest):
+    for key, (ps, ys, xs) in manifest["tile_origins"].items():
+        name, size = key.split("|")
+        h, w = map(int, size.split("x"))
+        fam, idx = name[:-3], int(name[-2])
+        entry = configs.PATCH_CONFIG[fam]
+        entry = entry[idx] if isinstance(entry, list) else entry
+        p = min(entry["patch_size"], max(h, w))
+        assert p == ps
+        assert utils.tile_origins(h, p, entry["patch_overlap"]) == ys
+        assert utils.tile_origins(w, p, entry["patch_overlap"]) == xs
+    # the headline case: 1280x720, Restormer deblur -> 2 x 3 tiles of 512
+    assert utils.tile_origins(720, 512, 96) == [0, 208] and utils.tile_origins(1280, 512, 96) == [0, 416, 768]
+
+
+def test_host_helpers_equal_oracle():
+    assert np.array_equal(utils.get_gaussian_weights(96, 96, 3), tiler_ref.gaussian_window(96, 96, 3))
+    t = gin("padcheck", (1, 3, 37, 50))
+    assert torch.equal(utils.pad(t), tiler_ref.reflect_pad8(t))
+    assert utils.pad(torch.zeros(1, 1, 16, 24)).shape == (1, 1, 16, 24)
+    img = np.arange(24, dtype=np.uint8).reshape(2, 4, 3)
+    assert np.array_equal(utils.normalize(img), tiler_ref.to_unit_range(img))
+    tl = gin("n2", (8, 8, 3)).numpy()
+    assert np.array_equal(utils.add_gaussian_noise(tl.copy(), 50), tiler_ref.degrade(tl, 50))
+
+
+def test_patch_config_dispatch():
+    assert utils.get_patch_config("denoising", "gaussian", "Restormer") == {"patch_size": 256, "patch_overlap": 48}
+    assert utils.get_patch_config("deblurring", "motion", "Restormer") == {"patch_size": 512, "patch_overlap": 96}
+    assert utils.get_patch_config("deblurring", "motion", "DeblurGANv2 (Inception)")["patch_size"] == 768
+    assert utils.get_patch_config("deblurring", "motion", "DeblurGANv2 (MobileNet)")["patch_size"] == 2048
+    assert utils.get_patch_config("denoising", "gaussian", "MaIR")["patch_size"] == 128
+    assert utils.get_patch_config("denoising", "real", "MaIR")["patch_size"] == 384
+    assert utils.get_patch_config("denoising", "gaussian", "DnCNN")["patch_overlap"] == 48
+    assert utils.get_patch_config("denoising", "gaussian", "REDNet")["patch_size"] == 128
+    assert utils.get_patch_config("denoising", "gaussian", "nothing") is None
+
+
+def test_model_factory_errors(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)                       # no weights/ directory here
+    with pytest.raises(FileNotFoundError):            # reference: propagates, callers skip (tests.py:48)
+        utils.get_model_instance("deblurring", "motion", "Restormer", torch.device("cpu"))
+    with pytest.raises(FileNotFoundError):
+        utils.get_model_instance("denoising", "gaussian", "DnCNN", torch.device("cpu"), gray=True)
+    with pytest.raises(ValueError, match="No model instance"):
+        utils.get_model_instance("deblurring", "motion", "DnCNN", torch.device("cpu"))
+
+
+def test_checkpoint_formats_load(tmp_path, monkeypatch, manifest):
+    """restormer: yml + {'params': sd}; dncnn: raw state dict strict; rednet: strict=False."""
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("weights/Restormer/deblurring")
+    os.makedirs("weights/DnCNN")
+    os.makedirs("weights/REDNet")
+    m = restormer.Restormer().load_synthetic(1)
+    torch.save({"params": m.state_dict()}, "weights/Restormer/deblurring/motion_deblurring.pth")
+    got = utils.get_model_instance("deblurring", "motion", "Restormer", torch.device("cpu"))
+    assert isinstance(got, restormer.Restormer) and not got.training
+    assert all(torch.equal(a, b) for a, b in zip(got.state_dict().values(), m.state_dict().values()))
+    d = dncnn.DnCNN(1, 1, 64, 20, "R").load_synthetic(2)
+    torch.save(d.state_dict(), "weights/DnCNN/dncnn_gray_blind.pth")
+    got = utils.get_model_instance("denoising", "gaussian", "DnCNN", torch.device("cpu"), gray=True)
+    assert got.nb == 20 and torch.equal(got.model[0].weight, d.model[0].weight)
+    r = rednet.REDNet().load_synthetic(3)
+    sd = r.state_dict()
+    sd.pop("conv3.bias")                              # strict=False tolerates a missing key
+    torch.save(sd, "weights/REDNet/25.pt")
+    got = utils.get_model_instance("denoising", "gaussian", "REDNet", torch.device("cpu"), sigma=25)
+    assert torch.equal(got.deconv15.weight, r.deconv15.weight)
+
+
+def test_product_modules_have_reference_parameter_layout(manifest):
+    for cfg, kw in {"deblur_withbias": dict(LayerNorm_type="WithBias"),
+                    "denoise_biasfree": dict(LayerNorm_type="BiasFree"),
+                    "gray_biasfree": dict(inp_channels=1, out_channels=1, LayerNorm_type="BiasFree"),
+                    "dualpixel_withbias": dict(inp_channels=6, dual_pixel_task=True)}.items():
+        mine = {k: list(v.shape) for k, v in restormer.Restormer(**kw).state_dict().items()}
+        assert mine == manifest["restormer_param_shapes"][cfg]
+    assert sum(p.numel() for p in restormer.Restormer().parameters()) == 26126644
+    for tag, (nch, nb) in {"gray17": (1, 17), "gray20": (1, 20), "color20": (3, 20)}.items():
+        mine = {k: list(v.shape) for k, v in dncnn.DnCNN(nch, nch, 64, nb, "R").state_dict().items()}
+        assert mine == manifest["dncnn_param_shapes"][tag]
+    assert {k: list(v.shape) for k, v in rednet.REDNet().state_dict().items()} == manifest["rednet_param_shapes"]
+
+
+def test_weight_packing_layout():
+    w = synth.uniform(1, "pw", (37, 29), -1, 1)
+    wp = _hip.pack_gemm_weight(w)
+    mt, ks = 3, 8
+    assert wp.numel() == mt * ks * 64
+    for (m, k) in [(0, 0), (5, 7), (36, 28), (17, 13)]:
+        lane = (m & 15) + 16 * (k & 3)
+        assert wp[((m >> 4) * ks + (k >> 2)) * 64 + lane] == w[m, k]
+    assert wp.abs().sum() == pytest.approx(float(w.abs().sum()), rel=1e-6)      # padding is zero
+    cw = synth.uniform(1, "cw", (20, 5, 3, 3), -1, 1)
+    cp = _hip.pack_conv3x3_weight(cw)
+    mt, ks = 2, 2
+    assert cp.numel() == 9 * mt * ks * 64
+    for (co, ci, ky, kx) in [(0, 0, 0, 0), (19, 4, 2, 1), (7, 3, 1, 2)]:
+        tap = ky * 3 + kx
+        lane = (co & 15) + 16 * (ci & 3)
+        assert cp[((tap * mt + (co >> 4)) * ks + (ci >> 2)) * 64 + lane] == cw[co, ci, ky, kx]
+    wt = synth.uniform(1, "dw", (4, 6, 3, 3), -1, 1)
+    x = synth.uniform(1, "dx", (1, 4, 7, 9), -1, 1)
+    ref = torch.nn.functional.conv_transpose2d(x, wt, padding=1)
+    got = torch.nn.functional.conv2d(x, _hip.deconv_as_conv_weight(wt), padding=1)
+    assert (ref - got).abs().max() < 1e-5
+    assert _hip.choose_ct(9) == 9 and _hip.choose_ct(16) == 8 and _hip.choose_ct(3) == 3 and _hip.choose_ct(12) == 6
+
+
+def test_metrics():
+    a = np.random.default_rng(0).integers(0, 256, (32, 40, 3)).astype(np.uint8)
+    b = np.clip(a.astype(int) + np.random.default_rng(1).integers(-3, 4, a.shape), 0, 255).astype(np.uint8)
+    p, s = utils.calculate_metrics(b, a)
+    assert p == pytest.approx(tiler_ref.psnr(a, b), abs=1e-12) and 0.9 < s <= 1.0
+    assert utils.calculate_metrics(a, a)[0] == float("inf")
+    assert utils.calculate_metrics(a, a)[1] == pytest.approx(1.0)
+
+
+def test_synth_is_deterministic():
+    a = synth.uniform(42, "x.weight", (4, 5), -1, 1)
+    assert torch.equal(a, synth.uniform(42, "x.weight", (4, 5), -1, 1))
+    assert not torch.equal(a, synth.uniform(43, "x.weight", (4, 5), -1, 1))
+    i1, t1 = synth.synth_image_pair(0, 48, 64)
+    i2, t2 = synth.synth_image_pair(0, 48, 64)
+    assert np.array_equal(i1, i2) and np.array_equal(t1, t2) and i1.dtype == np.uint8 and i1.shape == (48, 64, 3)
+    assert 15 < tiler_ref.psnr(t1, i1) < 45
+
+
+# --------------------------------------------------------------------------- C ABI
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "irm_hip.h")).read()
+    return sorted(set(re.findall(r"^\s*int\s+(irm_\w+)\s*\(", text, flags=re.M)))
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    names = _declared_symbols()
+    assert len(names) >= 10 and set(names) == set(_hip.SIGNATURES)
+    if not os.path.exists(_hip.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    for n in names:
+        assert getattr(lib, n) is not None
+    assert _hip.load().irm_version() == 1
+
+
+def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch):
+    m = restormer.Restormer()
+    with pytest.raises(_hip.HipLibraryError):
+        m(torch.zeros(1, 3, 8, 8))
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libirm_hip.so")
+    with pytest.raises(_hip.HipLibraryError, match="no CPU fallback"):
+        _hip.load()

@@ -1,0 +1,239 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against
+plain PyTorch fp32/fp64 references of the same op computed on the CPU.
+
+Tolerances: fp32 kernels vs an fp64 reference, absolute 2e-4 on O(1) data
+(the path's end-to-end budget is 1e-3 max-abs, BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from irm_amd import _hip, ops, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def rnd(name, shape, lo=-1.0, hi=1.0):
+    return synth.uniform(123, name, shape, lo, hi)
+
+
+def unpack_gemm(wp, M, K):
+    mt, ks = (M + 15) // 16, 4 * ((K + 15) // 16)
+    return wp.view(mt, ks, 4, 16).permute(0, 3, 1, 2).reshape(mt * 16, ks * 4)[:M, :K]
+
+
+def test_pack_roundtrip_cpu_side():
+    w = rnd("w", (37, 29))
+    assert torch.equal(unpack_gemm(_hip.pack_gemm_weight(w), 37, 29), w)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(1, 48, 8, 16), (2, 96, 12, 20), (3, 7, 4, 4), (1, 384, 8, 8), (2, 48, 5, 7)])
+def test_ln_stats(dev, B, C, H, W):
+    big = rnd(f"ln{B}{C}", (B, C + 5, H, W), -2, 3)
+    xb = big.to(dev)
+    x = xb[:, 2:2 + C]                         # channel slice: batch stride != C*H*W
+    stats = torch.empty(B, 2, H * W, device=dev)
+    ops.ln_stats(x, stats, 1e-5)
+    xr = big[:, 2:2 + C].double()
+    mean = xr.mean(1).reshape(B, -1)
+    rstd = 1.0 / torch.sqrt(xr.var(1, unbiased=False) + 1e-5).reshape(B, -1)
+    s = stats.cpu().double()
+    assert (s[:, 0] - mean).abs().max() < 1e-5
+    assert ((s[:, 1] - rstd).abs() / rstd).max() < 1e-5
+
+
+GEMM_CASES = [
+    # M, K, H, W, B, ln, res, bias, act, ct, yg
+    (144, 48, 16, 24, 2, 1, False, False, 0, None, None),
+    (144, 48, 16, 24, 1, 2, False, False, 0, 3, 2),
+    (48, 48, 8, 8, 2, 0, True, False, 0, None, None),
+    (254, 48, 16, 16, 1, 1, False, False, 0, None, None),
+    (48, 127, 16, 16, 2, 0, True, False, 0, None, None),
+    (96, 255, 8, 24, 1, 0, True, True, 0, None, None),
+    (288, 96, 16, 24, 1, 2, False, False, 0, None, 1),
+    (510, 96, 8, 16, 2, 1, False, True, 0, 8, 3),
+    (192, 384, 8, 8, 2, 0, False, False, 0, None, None),
+    (1152, 384, 8, 8, 1, 1, False, False, 0, None, None),
+    (2042, 384, 8, 8, 1, 2, False, False, 0, None, None),
+    (384, 1021, 8, 8, 2, 0, True, False, 0, None, None),
+    (40, 20, 4, 12, 1, 0, False, True, 2, 4, None),
+    (33, 50, 4, 12, 1, 0, True, True, 1, 6, None),
+    (64, 64, 12, 12, 1, 0, False, True, 3, 9, None),
+    (1152, 384, 5, 7, 2, 1, False, False, 0, None, None),     # odd N: scalar path
+    (384, 1021, 5, 7, 1, 0, True, False, 0, None, None),
+    (96, 48, 9, 15, 1, 2, True, True, 0, None, None),
+]
+
+
+@pytest.mark.parametrize("M,K,H,W,B,ln,res,bias,act,ct,yg", GEMM_CASES)
+def test_gemm1x1(dev, M, K, H, W, B, ln, res, bias, act, ct, yg):
+    tag = f"g{M}_{K}_{H}_{W}_{B}_{ln}"
+    w = rnd(tag + "w", (M, K), -0.3, 0.3)
+    x = rnd(tag + "x", (B, K, H, W), -1.5, 2.0)
+    r = rnd(tag + "r", (B, M, H, W)) if res else None
+    bv = rnd(tag + "b", (M,)) if bias else None
+    lnw = rnd(tag + "lw", (K,), 0.5, 1.5)
+    lnb = rnd(tag + "lb", (K,), -0.2, 0.2)
+    xd = x.double()
+    if ln:
+        mu = xd.mean(1, keepdim=True)
+        var = xd.var(1, unbiased=False, keepdim=True)
+        if ln == 1:
+            xn = (xd - mu) / torch.sqrt(var + 1e-5) * lnw.double().view(1, -1, 1, 1) + lnb.double().view(1, -1, 1, 1)
+        else:
+            xn = xd / torch.sqrt(var + 1e-5) * lnw.double().view(1, -1, 1, 1)
+    else:
+        xn = xd
+    ref = torch.einsum("mk,bkhw->bmhw", w.double(), xn)
+    if bias:
+        ref = ref + bv.double().view(1, -1, 1, 1)
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = F.gelu(ref)
+    elif act == 3:
+        ref = F.silu(ref)
+    if res:
+        ref = ref + r.double()
+
+    xg = x.to(dev)
+    stats = None
+    if ln:
+        stats = torch.empty(B, 2, H * W, device=dev)
+        ops.ln_stats(xg, stats)
+    ybig = torch.full((B, M + 3, H, W), 7.0, device=dev)     # write into a channel slice
+    y = ybig[:, 1:1 + M]
+    ops.gemm1x1(_hip.pack_gemm_weight(w).to(dev), xg, y, M, K, res=r.to(dev) if res else None,
+                bias=bv.to(dev) if bias else None, stats=stats, lnw=lnw.to(dev) if ln else None,
+                lnb=lnb.to(dev) if ln == 1 else None, ln_mode=ln, act=act, ct=ct, ygroups=yg)
+    got = ybig.cpu().double()
+    assert (got[:, 1:1 + M] - ref).abs().max() < TOL * max(1.0, float(ref.abs().max()))
+    assert torch.all(got[:, 0] == 7.0) and torch.all(got[:, 1 + M:] == 7.0)     # no stray writes
+
+
+def test_gemm1x1_inplace_residual_and_per_batch_weights(dev):
+    B, C, H, W = 3, 96, 8, 16
+    x = rnd("ipx", (B, C, H, W))
+    v = rnd("ipv", (B, C, H, W))
+    wb = rnd("ipw", (B, C, C), -0.2, 0.2)
+    packed = torch.stack([_hip.pack_gemm_weight(wb[b]) for b in range(B)]).to(dev)
+    xg = x.to(dev).clone()
+    ops.gemm1x1(packed, v.to(dev), xg, C, C, res=xg, w_bs=packed.shape[1])
+    ref = x.double() + torch.einsum("bmk,bkhw->bmhw", wb.double(), v.double())
+    assert (xg.cpu().double() - ref).abs().max() < TOL * 4
+
+
+@pytest.mark.parametrize("B,C,H,W,bias,act", [(2, 144, 16, 24, False, 0), (1, 7, 5, 8, True, 3), (1, 48, 64, 64, False, 0),
+                                               (2, 30, 9, 12, True, 0), (2, 33, 5, 7, False, 0), (1, 8, 17, 10, True, 3)])
+def test_dwconv3x3(dev, B, C, H, W, bias, act):
+    x = rnd(f"dw{C}{H}", (B, C, H, W))
+    w = rnd(f"dww{C}", (C, 1, 3, 3))
+    bv = rnd(f"dwb{C}", (C,)) if bias else None
+    ref = F.conv2d(x.double(), w.double(), bv.double() if bias else None, padding=1, groups=C)
+    if act == 3:
+        ref = F.silu(ref)
+    y = torch.empty(B, C, H, W, device=dev)
+    ops.dwconv3x3(x.to(dev), w.reshape(C, 9).to(dev), y, bias=bv.to(dev) if bias else None, act=act)
+    assert (y.cpu().double() - ref).abs().max() < TOL
+
+
+@pytest.mark.parametrize("B,hid,H,W", [(2, 127, 16, 24), (1, 255, 8, 8), (1, 5, 3, 4), (2, 1021, 5, 7)])
+def test_dwconv3x3_gate(dev, B, hid, H, W):
+    x = rnd(f"gt{hid}", (B, 2 * hid, H, W), -2, 2)
+    w = rnd(f"gtw{hid}", (2 * hid, 1, 3, 3))
+    d = F.conv2d(x.double(), w.double(), None, padding=1, groups=2 * hid)
+    ref = F.gelu(d[:, :hid]) * d[:, hid:]
+    y = torch.empty(B, hid, H, W, device=dev)
+    ops.dwconv3x3_gate(x.to(dev), w.reshape(-1, 9).to(dev), y)
+    assert (y.cpu().double() - ref).abs().max() < TOL
+
+
+@pytest.mark.parametrize("B,C,heads,H,W", [(2, 48, 1, 16, 24), (1, 96, 2, 16, 16), (2, 96, 1, 8, 40), (1, 192, 4, 8, 8),
+                                           (1, 384, 8, 8, 8), (1, 64, 2, 8, 8), (1, 32, 2, 8, 8), (1, 48, 1, 64, 80), (2, 384, 8, 5, 7), (1, 96, 1, 9, 15)])
+def test_mdta_fold(dev, B, C, heads, H, W):
+    N, c = H * W, C // heads
+    qkv = rnd(f"md{C}{heads}{H}", (B, 3 * C, H, W))
+    temp = rnd(f"mdt{C}{heads}", (heads,), 2.0, 6.0)
+    wout = rnd(f"mdw{C}", (C, C), -0.3, 0.3)
+    q, k, v = qkv.double().reshape(B, 3, heads, c, N).unbind(1)
+    qn, kn = F.normalize(q, dim=-1), F.normalize(k, dim=-1)
+    attn = torch.softmax(qn @ kn.transpose(-1, -2) * temp.double().view(1, heads, 1, 1), dim=-1)
+    ref = torch.einsum("oc,bcn->bon", wout.double(), (attn @ v).reshape(B, C, N)).reshape(B, C, H, W)
+
+    chunk, nchunk, rec = ops.mdta_plan(B, C, heads, N)
+    part = torch.full((B * heads * nchunk * rec,), float("nan"), device=dev)
+    gsum = torch.empty(B * heads * rec, device=dev)
+    mfold = torch.zeros(B * ops.mfold_numel(C), device=dev)
+    attn_out = torch.empty(B, heads, c, c, device=dev)
+    qg = qkv.to(dev)
+    ops.mdta_fold(qg, part, gsum, temp.to(dev), wout.to(dev), mfold, C, heads, attn=attn_out)
+    assert (attn_out.cpu().double() - attn).abs().max() < 2e-5
+    y = torch.empty(B, C, H, W, device=dev)
+    ops.gemm1x1(mfold, qg[:, 2 * C:], y, C, C, w_bs=ops.mfold_numel(C))
+    assert (y.cpu().double() - ref).abs().max() < TOL
+
+
+CONV_CASES = [
+    # ci, co, H, W, B, bias, relu1, res_mode, relu2, store
+    (3, 48, 16, 32, 2, False, False, 0, False, 0),
+    (48, 24, 16, 32, 1, False, False, 0, False, 1),
+    (96, 48, 8, 40, 2, False, False, 0, False, 1),
+    (96, 192, 8, 16, 1, False, False, 0, False, 2),
+    (384, 768, 8, 8, 1, False, False, 0, False, 2),
+    (96, 3, 24, 40, 2, False, False, 1, False, 0),
+    (1, 64, 13, 21, 1, True, True, 0, False, 0),
+    (64, 64, 13, 21, 2, True, True, 0, False, 0),
+    (64, 1, 13, 21, 1, True, False, 2, False, 0),
+    (128, 128, 16, 16, 1, True, True, 1, True, 0),
+    (6, 48, 9, 33, 1, True, False, 0, False, 0),
+    (192, 96, 10, 14, 1, False, False, 0, False, 1),     # unshuffle, W % 4 != 0
+    (384, 768, 5, 7, 2, False, False, 0, False, 2),       # shuffle at an odd level-4 size
+]
+
+
+@pytest.mark.parametrize("ci,co,H,W,B,bias,relu1,res_mode,relu2,store", CONV_CASES)
+def test_conv3x3(dev, ci, co, H, W, B, bias, relu1, res_mode, relu2, store):
+    tag = f"cv{ci}_{co}_{H}_{W}"
+    x = rnd(tag + "x", (B, ci, H, W))
+    w = rnd(tag + "w", (co, ci, 3, 3), -0.2, 0.2)
+    bv = rnd(tag + "b", (co,)) if bias else None
+    ref = F.conv2d(x.double(), w.double(), bv.double() if bias else None, padding=1)
+    if relu1:
+        ref = torch.relu(ref)
+    r = None
+    if res_mode:
+        r = rnd(tag + "r", (B, co, H, W))
+        ref = ref + r.double() if res_mode == 1 else r.double() - ref
+    if relu2:
+        ref = torch.relu(ref)
+    if store == 1:
+        ref = F.pixel_unshuffle(ref, 2)
+    elif store == 2:
+        ref = F.pixel_shuffle(ref, 2)
+    ybig = torch.full((B, ref.shape[1] + 2, ref.shape[2], ref.shape[3]), 5.0, device=dev)
+    y = ybig[:, 1:1 + ref.shape[1]]
+    ops.conv3x3(_hip.pack_conv3x3_weight(w).to(dev), x.to(dev), y, ci, co, bias=bv.to(dev) if bias else None,
+                relu1=relu1, res=r.to(dev) if res_mode else None, res_mode=res_mode, relu2=relu2, store_mode=store)
+    got = ybig.cpu().double()
+    assert (got[:, 1:-1] - ref).abs().max() < TOL * max(1.0, float(ref.abs().max()))
+    assert torch.all(got[:, 0] == 5.0) and torch.all(got[:, -1] == 5.0)
+
+
+def test_deconv_as_conv(dev):
+    wt = rnd("dcw", (32, 16, 3, 3), -0.3, 0.3)      # ConvTranspose2d weight [Ci][Co][3][3]
+    x = rnd("dcx", (1, 32, 10, 12))
+    ref = F.conv_transpose2d(x.double(), wt.double(), None, padding=1)
+    y = torch.empty(1, 16, 10, 12, device=dev)
+    ops.conv3x3(_hip.pack_conv3x3_weight(_hip.deconv_as_conv_weight(wt)).to(dev), x.to(dev), y, 32, 16)
+    assert (y.cpu().double() - ref).abs().max() < TOL
+
+
+def test_rejects_bad_arguments(dev):
+    x = torch.zeros(1, 4, 3, 5, device=dev)
+    with pytest.raises(_hip.HipLibraryError):      # act code out of range -> IRM_EINVAL, nothing launched
+        ops.dwconv3x3(x, torch.zeros(4, 9, device=dev), torch.empty_like(x), act=9)
+    with pytest.raises(_hip.HipLibraryError):      # PixelUnshuffle needs even H, W
+        ops.conv3x3(torch.zeros(9 * 64, device=dev), x, torch.empty(1, 16, 1, 2, device=dev), 4, 4, store_mode=1)
+    with pytest.raises(ValueError):
+        ops.ln_stats(torch.zeros(1, 4, 4, 4), torch.zeros(32))          # CPU tensor
