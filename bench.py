@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): images/s + PSNR, Restormer motion-deblur
+on 1280x720 GoPro-shaped synthetic uint8 frames, one image per GPU per step.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = the whole tiled-patch hot path for ONE frame per rank (reference:
+src/utils.py:353-454 + src/restormer/restormer.py): tile extraction (6 tiles of
+512x512, overlap 96), the batched Restormer forward in libirm_hip.so, the
+Gaussian-window blend + requantisation, and the squared error vs the target.
+Frames are resident in HBM before the timed region; the uint8 result stays on
+the device.  Images are independent units: rank r processes its own frames, no
+data-path collective; PSNR rows are gathered once at the end (RCCL all_gather).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
+(the dominant kernel: the f32-MFMA 1x1 GEMM, timed with HIP events on the launch
+stream during the timed steps) and `cpu_baseline` (the CPU oracle on the host
+cores over a bounded sample, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import irm_amd  # noqa: E402,F401
+from irm_amd import ops, restormer, synth, utils  # noqa: E402
+from irm_amd.configs import PATCH_CONFIG  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+PEAK_HBM_GBS = 8000.0             # HBM3E spec peak
+H, W, C = 720, 1280, 3
+N_FRAMES = 4                      # distinct synthetic frames per rank, cycled over the steps
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
+    ap.add_argument("--no-kernel-timer", action="store_true", help="no per-launch events in the timed steps")
+    ap.add_argument("--cpu-tile", type=int, default=512, help="tile edge of the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(model, frame_u8, gpu_tile, tile_edge):
+    """Oracle (PyTorch-CPU restatement of the reference forward, pinned to the reference by
+    oracle/gen_golden.py) on a bounded sample: ONE tile of the first frame, all host threads."""
+    from oracle import restormer_ref, tiler_ref
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    x = tiler_ref.to_unit_range(frame_u8)[:tile_edge, :tile_edge]
+    t = torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))[None]
+    threads = torch.get_num_threads()
+    t0 = time.time()
+    with torch.no_grad():
+        y = restormer_ref.restormer_forward(t, sd)
+    dt = time.time() - t0
+    tiles_per_image = 6 * (512.0 / tile_edge) ** 2
+    out = dict(value=1.0 / (dt * tiles_per_image), unit="images/s", cores=threads, kind="port",
+               sample=f"1 tile {tile_edge}x{tile_edge} of frame 0 through the oracle Restormer forward "
+                      f"({dt:.1f} s on {threads} torch threads, os.cpu_count={os.cpu_count()}); "
+                      f"image rate = 1/({tiles_per_image:g} x tile time), tiler cost excluded")
+    if gpu_tile is not None and tile_edge == 512:
+        out["max_abs_vs_gpu_tile0"] = float((y[0] - gpu_tile.cpu()).abs().max())
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    model = restormer.Restormer(LayerNorm_type="WithBias").load_synthetic(42).eval().to(dev)
+    cfg = PATCH_CONFIG["Restormer"][1]                      # deblurring: 512 / 96
+    frames, targets, host_frames = [], [], []
+    for i in range(N_FRAMES):
+        inp, tgt = synth.synth_image_pair(rank * 1000 + i, H, W, C, seed_base=1000, blur=15)
+        host_frames.append((inp, tgt))
+        frames.append(torch.from_numpy(inp).to(dev))
+        targets.append(torch.from_numpy(tgt).to(dev))
+
+    def step(i, keep=None):
+        return utils.tiled_forward_device(model, frames[i % N_FRAMES], cfg["patch_size"], cfg["patch_overlap"],
+                                          pad8=True, target_dev=targets[i % N_FRAMES],
+                                          max_batch=model.max_tiles_per_batch, keep_tiles=keep)
+
+    keep = []
+    for i in range(args.warmup):
+        step(i, keep if i == 0 else None)
+    torch.cuda.synchronize()
+
+    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    results = [step(i) for i in range(args.steps)]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+
+    # max over ranks, PSNR rows gathered once (tens of bytes per image)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rows = torch.tensor([[rank * args.steps + i, float(10 * np.log10(255.0 ** 2 / max(float(s.item()) / (H * W * C), 1e-12)))]
+                         for i, (_, s) in enumerate(results)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        allrows = [torch.empty_like(rows) for _ in range(world)]
+        dist.all_gather(allrows, rows)
+        rows = torch.cat(allrows)
+    elapsed = float(el.item())
+    psnr = rows[:, 1].cpu().numpy()
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec + PSNR, Restormer motion-deblur 1280x720",
+            "value": world * args.steps / elapsed, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Restormer motion-deblur (WithBias LN, 26.13M params, synthetic weights seed 42) on "
+                                   "1280x720x3 uint8 GoPro-shaped synthetic frames; 6 tiles 512x512 (overlap 96) per "
+                                   "frame, batched; one frame per GPU per step",
+                       "global_batch": world, "tile": cfg["patch_size"], "overlap": cfg["patch_overlap"],
+                       "parallelism": f"per-image shard x{world}, no data-path collective"},
+            "psnr_db_mean": float(psnr.mean()), "psnr_db_std": float(psnr.std()),
+        }
+        if timer is not None:
+            ks = timer.summary()
+            tot_ms = sum(k["ms"] for k in ks.values())
+            g = ks["gemm1x1"]
+            tfl = g["flops"] / (g["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "gemm_pw_kernel (irm_gemm1x1_f32)", "bound": "mfma", "achieved": tfl,
+                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_F32_MFMA_TFLOPS,
+                               "traffic": None, "launches": g["launches"],
+                               "avg_launch_us": g["ms"] * 1e3 / g["launches"],
+                               "share_of_kernel_time": g["ms"] / tot_ms}
+            out["kernels"] = {
+                k: {"launches": v["launches"], "ms_per_step": v["ms"] / args.steps,
+                    "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12, "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
+                    "hbm_frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+                for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])}
+            # whole-step bound: max(F/peakF, B/peakB) / t  
+            F = sum(v["flops"] for v in ks.values()) / args.steps
+            Bt = sum(v["bytes"] for v in ks.values()) / args.steps
+            bound_s = max(F / (PEAK_F32_MFMA_TFLOPS * 1e12), Bt / (PEAK_HBM_GBS * 1e9))
+            out["step_model"] = {"gflop": F / 1e9, "gbytes": Bt / 1e9, "bound_ms": bound_s * 1e3,
+                                 "frac_of_bound": bound_s / (elapsed / args.steps)}
+        if world == 1 and not args.no_cpu_baseline:
+            gpu_tile = keep[0][0] if keep else None
+            out["cpu_baseline"] = cpu_baseline(model, host_frames[0][0], gpu_tile, args.cpu_tile)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

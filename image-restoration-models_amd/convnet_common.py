@@ -3,20 +3,12 @@ from __future__ import annotations
 
 import torch
 
-from . import _hip
+from . import _hip, ops
 
 
 def conv3x3(wp, x, y, ci, co, bias=None, relu1=False, res=None, res_mode=0, relu2=False):
     """y = epilogue(conv3x3(x)) through irm_conv3x3_f32 (include/irm_hip.h)."""
-    B, _, H, W = x.shape
-    mt = (co + 15) // 16
-    ct = _hip.choose_ct(mt, (6, 4, 3, 2, 1))
-    nchunks = -(-mt // ct)
-    blocks = -(-W // 32) * -(-H // 8) * B
-    yg = max(1, min(nchunks, -(-1024 // blocks)))
-    _hip.call("irm_conv3x3_f32", _hip.ptr(wp), _hip.ptr(x), x.stride(0), _hip.ptr(y), y.stride(0),
-              _hip.ptr(res), res.stride(0) if res is not None else 0, _hip.ptr(bias), B, ci, co, H, W,
-              int(relu1), res_mode, int(relu2), 0, ct, yg)
+    ops.conv3x3(wp, x, y, ci, co, bias=bias, relu1=relu1, res=res, res_mode=res_mode, relu2=relu2)
 
 
 class PackedCache:

@@ -20,6 +20,7 @@
 //    (zero padded; ksteps padded to a multiple of 4) and staged through LDS
 //    with plain 16-byte copies.
 #include "irm_common.h"
+#include <stdlib.h>
 
 struct GemmArgs {
     const float* Wp; long w_bs;   // packed weights, per-batch stride (0 = shared)
@@ -190,6 +191,228 @@ __global__ __launch_bounds__(256) void gemm_pw_kernel(GemmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fast path (every operand row 16-byte aligned, N % 4 == 0): the same GEMM as an
+// NS-deep LDS-DMA ring.  X rows (16 channels x 128 pixels = 8 KiB) and the
+// packed weights of the pass (CT KiB) are copied global -> LDS by
+// global_load_lds_dwordx4 (no VGPR staging), NS-1 stages stay in flight across
+// the per-stage barrier behind a counted s_waitcnt vmcnt(N), and the pipeline
+// runs on over pass boundaries, so the epilogue stores of one pass overlap the
+// loads of the next.  The LayerNorm prologue moves to the LDS -> register read:
+// a = ((x - mu) * rstd) * w[k] + b[k] costs 2 FMAs per A fragment, 18 MFMAs apart.
+// Out-of-range rows / columns / tiles are handled by clamping the source
+// address (their products meet zero-padded weights or are never stored), so
+// the DMA needs no masking and LDS never holds uninitialised bits.
+__device__ __attribute__((noinline)) float irm_act_slow(float v, int act) { return irm_act(v, act); }
+
+template <int N>
+__device__ __forceinline__ void irm_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int CT, int NS, int LN>
+__global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
+    constexpr int BN = 128, BK = 16;
+    constexpr int XS = BK * BN;                 // floats of X per stage
+    constexpr int STG = XS + CT * 256;          // floats per stage
+    constexpr int WL = (CT + 3) / 4;            // weight DMA instructions per wave per stage
+    constexpr int LPS = 2 + WL;                 // DMA instructions per wave per stage
+    static_assert((NS - 2) * LPS <= 63, "vmcnt field");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.x * BN;
+    const float* X = a.X + (long)b * a.x_bs;
+    const float* Wp = a.Wp + (long)b * a.w_bs;
+    float* Y = a.Y + (long)b * a.y_bs;
+    const float* R = a.R ? a.R + (long)b * a.r_bs : nullptr;
+    const int KP = a.ksteps * 4;
+    float* lnp = smem + NS * STG;               // [2][KP]: LN weight, LN bias (zero padded)
+
+    float rs[2] = {1.f, 1.f}, nmr[2] = {0.f, 0.f};
+    if (LN != IRM_LN_NONE) {
+        const float* st = a.stats + (long)b * 2 * a.N;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int pix = min(n0 + wave * 32 + p * 16 + r, a.N - 1);
+            const float m = st[pix], q = st[a.N + pix];
+            rs[p] = q;
+            nmr[p] = -m * q;
+        }
+        for (int i = tid; i < KP; i += 256) {
+            lnp[i] = i < a.K ? a.lnw[i] : 0.0f;
+            lnp[KP + i] = (LN == IRM_LN_WITHBIAS && i < a.K) ? a.lnb[i] : 0.0f;
+        }
+        __syncthreads();                         // before any DMA is in flight
+    }
+
+    const int S = a.ksteps / 4;
+    const int nchunks = (a.mtiles + CT - 1) / CT;
+    const int my_chunks = (nchunks - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int TOT = my_chunks * S;
+
+    const int xrow = 4 * wave + (lane >> 5);
+    const int xcol = min(n0 + (lane & 31) * 4, a.N - 4);
+
+    auto issue = [&](int it) {
+        const int ci = it / S, s = it - ci * S;
+        const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
+        float* xb = smem + (it % NS) * STG;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = min(s * BK + xrow + 2 * j, a.K - 1);
+            const float* src = X + (long)k * a.N + xcol;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xb + (4 * wave + 2 * j) * BN),
+                                             16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WL; ++i) {
+            const int ct = min(wave + 4 * i, CT - 1);
+            const int mt = min(mt0 + ct, a.mtiles - 1);
+            const float* src = Wp + ((long)mt * a.ksteps + s * 4) * 64 + lane * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xb + XS + ct * 256), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int pixs[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) pixs[p] = n0 + wave * 32 + p * 16 + g * 4;
+    // residual / bias of the running pass: loaded (clamped addresses, back to back) during the
+    // pass's first stage and first used in its epilogue, so their latency hides under the MFMAs
+    float4 rv[2][CT];
+    float bvs[CT];
+
+#pragma unroll
+    for (int j = 0; j < NS - 1; ++j)
+        if (j < TOT) issue(j);
+
+    int s = 0, ci = 0;
+    for (int it = 0; it < TOT; ++it) {
+        // stage `it` has landed once at most `rem` younger stages are still in flight
+        const int rem = min(NS - 2, TOT - 1 - it);
+        if (rem >= 2 && NS >= 4) irm_wait_vmcnt<2 * LPS>();
+        else if (rem == 1 && NS >= 3) irm_wait_vmcnt<LPS>();
+        else irm_wait_vmcnt<0>();
+        asm volatile("s_barrier" ::: "memory");
+        if (it + NS - 1 < TOT) issue(it + NS - 1);
+        if (s == 0) {
+            const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
+            if (R) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const long row = (long)min((mt0 + c) * 16 + r, a.M - 1) * a.N;
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        rv[p][c] = *reinterpret_cast<const float4*>(R + row + min(pixs[p], a.N - 4));
+                }
+            }
+            if (a.bias) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) bvs[c] = a.bias[min((mt0 + c) * 16 + r, a.M - 1)];
+            }
+        }
+
+        const float* xb = smem + (it % NS) * STG;
+        const float* wb = xb + XS;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float af[2], bf[CT];
+            float wk = 1.f, bk = 0.f;
+            if (LN != IRM_LN_NONE) {
+                wk = lnp[s * BK + kk * 4 + g];
+                if (LN == IRM_LN_WITHBIAS) bk = lnp[KP + s * BK + kk * 4 + g];
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float x = xb[(kk * 4 + g) * BN + wave * 32 + p * 16 + r];
+                if (LN == IRM_LN_WITHBIAS) af[p] = fmaf(fmaf(x, rs[p], nmr[p]), wk, bk);
+                else if (LN == IRM_LN_BIASFREE) af[p] = x * rs[p] * wk;
+                else af[p] = x;
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) bf[c] = wb[(c * 4 + kk) * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) acc[p][c] = irm_mfma16(af[p], bf[c], acc[p][c]);
+        }
+
+        if (++s == S) {
+            // pass finished: (+ bias, activation, + residual) and store tiles mt0 .. mt0 + CT - 1
+            const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
+            if (a.bias) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) acc[p][c] += bvs[c];
+            }
+            if (a.act != IRM_ACT_NONE) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[p][c][e] = irm_act_slow(acc[p][c][e], a.act);
+            }
+            if (R) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        acc[p][c][0] += rv[p][c].x; acc[p][c][1] += rv[p][c].y;
+                        acc[p][c][2] += rv[p][c].z; acc[p][c][3] += rv[p][c].w;
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int co = (mt0 + c) * 16 + r;
+                const bool row_ok = mt0 + c < a.mtiles && co < a.M;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    if (row_ok && pixs[p] < a.N)
+                        *reinterpret_cast<float4*>(Y + (long)co * a.N + pixs[p]) =
+                            make_float4(acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]);
+                    acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            s = 0;
+            ++ci;
+        }
+    }
+}
+
+template <int CT, int LN>
+static int launch_ring(const GemmArgs& a, int B, int ygroups, hipStream_t stream) {
+    constexpr int NS = 4;
+    const size_t lds = ((size_t)NS * (16 * 128 + CT * 256) + 2 * (size_t)a.ksteps * 4) * sizeof(float);
+    static bool configured = false;              // per instantiation
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<CT, NS, LN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return IRM_ELAUNCH;
+        configured = true;
+    }
+    dim3 grid((a.N + 127) / 128, ygroups, B);
+    hipLaunchKernelGGL((gemm_ring_kernel<CT, NS, LN>), grid, dim3(256), lds, stream, a);
+    return irm_launch_status();
+}
+
+template <int CT>
+static int launch_ring_ln(const GemmArgs& a, int B, int ygroups, hipStream_t stream) {
+    if (a.ln_mode == IRM_LN_WITHBIAS) return launch_ring<CT, IRM_LN_WITHBIAS>(a, B, ygroups, stream);
+    if (a.ln_mode == IRM_LN_BIASFREE) return launch_ring<CT, IRM_LN_BIASFREE>(a, B, ygroups, stream);
+    return launch_ring<CT, IRM_LN_NONE>(a, B, ygroups, stream);
+}
+
 template <int PT, int CT>
 static int launch_gemm(const GemmArgs& a, int B, int ygroups, bool vec, hipStream_t stream) {
     constexpr int BN = 64 * PT;
@@ -201,6 +424,10 @@ static int launch_gemm(const GemmArgs& a, int B, int ygroups, bool vec, hipStrea
 
 // ---------------------------------------------------------------------------
 // C ABI (declared in include/irm_hip.h)
+static bool irm_force_generic() {
+    static const bool v = getenv("IRM_GEMM_GENERIC") != nullptr;   // A/B switch for benchmarking only
+    return v;
+}
 extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long x_bs, float* y, long y_bs,
                                const float* res, long r_bs, const float* bias, const float* stats,
                                const float* lnw, const float* lnb, int ln_mode, int act, int B, int M, int K,
@@ -221,6 +448,16 @@ extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long 
     if (ygroups <= 0) ygroups = 1;
     if (ygroups > nchunks) ygroups = nchunks;
     if (B > 65535 || ygroups > 65535) return IRM_EINVAL;
+    if (vec && N >= 4 && !irm_force_generic()) {
+        switch (ct) {
+            case 3: return launch_ring_ln<3>(a, B, ygroups, stream);
+            case 4: return launch_ring_ln<4>(a, B, ygroups, stream);
+            case 6: return launch_ring_ln<6>(a, B, ygroups, stream);
+            case 8: return launch_ring_ln<8>(a, B, ygroups, stream);
+            case 9: return launch_ring_ln<9>(a, B, ygroups, stream);
+            default: return IRM_EINVAL;
+        }
+    }
     switch (ct) {
         case 3: return launch_gemm<2, 3>(a, B, ygroups, vec, stream);
         case 4: return launch_gemm<2, 4>(a, B, ygroups, vec, stream);

@@ -13,6 +13,48 @@ from . import _hip
 from ._hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU, LN_BIASFREE, LN_NONE, LN_WITHBIAS  # noqa: F401
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing (bench.py's roofline leg).
+
+    While an instance is installed as ``ops.TIMER`` every wrapper below brackets
+    its launch with two events on the launch stream (torch's current stream) and
+    logs the call's algorithmic FLOPs and compulsory bytes (inputs read once,
+    outputs written once, fp32).  ``summary()`` synchronises and aggregates."""
+
+    def __init__(self):
+        self.records = []          # (kernel, start_event, end_event, flops, bytes)
+
+    def launch(self, kernel, fn, flops=0.0, nbytes=0.0):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.records.append((kernel, e0, e1, float(flops), float(nbytes)))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for k, e0, e1, fl, by in self.records:
+            d = out.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+#: set to a KernelTimer to time launches; None = plain launches
+TIMER: KernelTimer | None = None
+
+
+def _launch(kernel, flops, nbytes, name, *args):
+    if TIMER is None:
+        _hip.call(name, *args)
+    else:
+        TIMER.launch(kernel, lambda: _hip.call(name, *args), flops, nbytes)
+
+
 def _chk(t: torch.Tensor, name: str):
     if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4):
         raise ValueError(f"{name}: expected a float32 CUDA tensor [B,C,H,W]")
@@ -36,7 +78,9 @@ def ln_stats(x: torch.Tensor, stats: torch.Tensor, eps: float = 1e-5):
     _chk(x, "x")
     B, C, H, W = x.shape
     assert stats.numel() >= B * 2 * H * W and stats.is_contiguous()
-    _hip.call("irm_ln_stats_f32", _hip.ptr(x), _bs(x), _hip.ptr(stats), B, C, H * W, float(eps))
+    N = H * W
+    _launch("ln_stats", 5.0 * B * C * N, 4.0 * B * N * (C + 2), "irm_ln_stats_f32", _hip.ptr(x), _bs(x),
+            _hip.ptr(stats), B, C, N, float(eps))
 
 
 def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, *, res=None, bias=None,
@@ -56,25 +100,26 @@ def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, 
         nchunks = -(-mt // ct)
         blocks = -(-N // 128) * B
         ygroups = max(1, min(nchunks, -(-target_blocks() // blocks)))
-    _hip.call("irm_gemm1x1_f32", _hip.ptr(wp), int(w_bs), _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y),
-              _hip.ptr(res), _bs(res), _hip.ptr(bias), _hip.ptr(stats), _hip.ptr(lnw), _hip.ptr(lnb),
-              int(ln_mode), int(act), B, M, K, N, ct, ygroups)
+    nbytes = 4.0 * B * N * (K + M + (M if res is not None else 0) + (2 if stats is not None else 0))
+    _launch("gemm1x1", 2.0 * B * M * K * N, nbytes, "irm_gemm1x1_f32", _hip.ptr(wp), int(w_bs), _hip.ptr(x), _bs(x),
+            _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), _hip.ptr(stats), _hip.ptr(lnw),
+            _hip.ptr(lnb), int(ln_mode), int(act), B, M, K, N, ct, ygroups)
 
 
 def dwconv3x3(x, w9, y, *, bias=None, act=ACT_NONE):
     """Depth-wise 3x3 (+bias, +activation); w9: [C, 9]."""
     _chk(x, "x"), _chk(y, "y")
     B, C, H, W = x.shape
-    _hip.call("irm_dwconv3x3_f32", _hip.ptr(x), _bs(x), _hip.ptr(w9), _hip.ptr(bias), _hip.ptr(y), _bs(y),
-              B, C, H, W, int(act))
+    _launch("dwconv3x3", 18.0 * B * C * H * W, 8.0 * B * C * H * W, "irm_dwconv3x3_f32", _hip.ptr(x), _bs(x),
+            _hip.ptr(w9), _hip.ptr(bias), _hip.ptr(y), _bs(y), B, C, H, W, int(act))
 
 
 def dwconv3x3_gate(x, w9, y, *, bias=None):
     """GDFN: y[:, c] = gelu(dw(x[:, c])) * dw(x[:, c + hid]); x has 2*hid channels."""
     _chk(x, "x"), _chk(y, "y")
     B, C2, H, W = x.shape
-    _hip.call("irm_dwconv3x3_gate_f32", _hip.ptr(x), _bs(x), _hip.ptr(w9), _hip.ptr(bias), _hip.ptr(y), _bs(y),
-              B, C2 // 2, H, W)
+    _launch("dwconv3x3_gate", 18.0 * B * C2 * H * W, 4.0 * B * (C2 + C2 // 2) * H * W, "irm_dwconv3x3_gate_f32",
+            _hip.ptr(x), _bs(x), _hip.ptr(w9), _hip.ptr(bias), _hip.ptr(y), _bs(y), B, C2 // 2, H, W)
 
 
 def mdta_plan(B: int, C: int, heads: int, N: int):
@@ -94,9 +139,12 @@ def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, att
     N = H * W
     chunk, nchunk, rec = mdta_plan(B, C, heads, N)
     assert part.numel() >= B * heads * nchunk * rec and gsum.numel() >= B * heads * rec
-    _hip.call("irm_mdta_gram_f32", _hip.ptr(qkv), _bs(qkv), _hip.ptr(part), B, C, heads, N, chunk)
-    _hip.call("irm_mdta_finalize_f32", _hip.ptr(part), _hip.ptr(gsum), _hip.ptr(temperature), _hip.ptr(wout),
-              _hip.ptr(mfold), _hip.ptr(attn), B, C, heads, nchunk)
+    c = C // heads
+    _launch("mdta_gram", 2.0 * B * heads * c * c * N, 8.0 * B * C * N, "irm_mdta_gram_f32", _hip.ptr(qkv), _bs(qkv),
+            _hip.ptr(part), B, C, heads, N, chunk)
+    _launch("mdta_finalize", 2.0 * B * C * C * c, 4.0 * B * (heads * nchunk * rec + C * C), "irm_mdta_finalize_f32",
+            _hip.ptr(part), _hip.ptr(gsum), _hip.ptr(temperature), _hip.ptr(wout), _hip.ptr(mfold), _hip.ptr(attn),
+            B, C, heads, nchunk)
 
 
 def mfold_numel(C: int) -> int:
@@ -116,5 +164,7 @@ def conv3x3(wp, x, y, ci: int, co: int, *, bias=None, relu1=False, res=None, res
         nchunks = -(-mt // ct)
         blocks = -(-W // 32) * -(-H // 8) * B
         ygroups = max(1, min(nchunks, -(-target_blocks() // blocks)))
-    _hip.call("irm_conv3x3_f32", _hip.ptr(wp), _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res),
-              _hip.ptr(bias), B, ci, co, H, W, int(relu1), int(res_mode), int(relu2), int(store_mode), ct, ygroups)
+    nbytes = 4.0 * B * H * W * (ci + co + (co if res is not None else 0))
+    _launch("conv3x3", 18.0 * B * ci * co * H * W, nbytes, "irm_conv3x3_f32", _hip.ptr(wp), _hip.ptr(x), _bs(x),
+            _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), B, ci, co, H, W, int(relu1), int(res_mode),
+            int(relu2), int(store_mode), ct, ygroups)
