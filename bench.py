@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
     ap.add_argument("--no-kernel-timer", action="store_true", help="no per-launch events in the timed steps")
+    ap.add_argument("--streams", type=int, default=1, help="tile groups run on this many HIP streams")
+    ap.add_argument("--detail", default=None, help="write a per-shape kernel table (json) to this path")
     ap.add_argument("--cpu-tile", type=int, default=512, help="tile edge of the CPU-baseline sample")
     return ap.parse_args()
 
@@ -93,6 +95,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     model = restormer.Restormer(LayerNorm_type="WithBias").load_synthetic(42).eval().to(dev)
+    model.num_streams = args.streams
     cfg = PATCH_CONFIG["Restormer"][1]                      # deblurring: 512 / 96
     frames, targets, host_frames = [], [], []
     for i in range(N_FRAMES):
@@ -111,7 +114,7 @@ def main():
         step(i, keep if i == 0 else None)
     torch.cuda.synchronize()
 
-    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    timer = None if args.no_kernel_timer else ops.KernelTimer(detail=args.detail is not None)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -152,6 +155,18 @@ def main():
         }
         if timer is not None:
             ks = timer.summary()
+            if args.detail:
+                rows = {k: {"launches": v["launches"], "us_per_launch": v["ms"] * 1e3 / v["launches"],
+                            "ms_per_step": v["ms"] / args.steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                            "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k, v in ks.items()}
+                with open(args.detail, "w") as f:
+                    json.dump(dict(sorted(rows.items(), key=lambda kv: -kv[1]["ms_per_step"])), f, indent=1)
+                agg = {}
+                for k, v in ks.items():
+                    d = agg.setdefault(k.split(" ")[0], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+                    for f_ in d:
+                        d[f_] += v[f_]
+                ks = agg
             tot_ms = sum(k["ms"] for k in ks.values())
             g = ks["gemm1x1"]
             tfl = g["flops"] / (g["ms"] * 1e-3) / 1e12

@@ -10,19 +10,44 @@
 template <bool VEC>
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, long x_bs,
                                                        float* __restrict__ stats, int C, int N, float eps) {
+    // 64 pixel quads x 4 channel groups per workgroup: wave w runs Welford over channels w, w+4, ...
+    // (every load is a contiguous 1 KiB row segment); the four partials are merged in wave order.
+    __shared__ float4 pm[4][64], pq[4][64];
     const int b = blockIdx.y;
-    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (n >= N) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = (blockIdx.x * 64 + lane) * 4;
     const float* p = x + (long)b * x_bs;
     float4 mean = make_float4(0.f, 0.f, 0.f, 0.f), m2 = mean;
-    for (int c = 0; c < C; ++c) {
-        const float4 v = irm_ld4<VEC>(p + (long)c * N, n, N);
-        const float rc = 1.0f / (float)(c + 1);
+    int cnt = 0;
+    if (n < N) {
+        for (int c = w; c < C; c += 4) {
+            const float4 v = irm_ld4<VEC>(p + (long)c * N, n, N);
+            const float rc = 1.0f / (float)(++cnt);
+            float d;
+            d = v.x - mean.x; mean.x += d * rc; m2.x += d * (v.x - mean.x);
+            d = v.y - mean.y; mean.y += d * rc; m2.y += d * (v.y - mean.y);
+            d = v.z - mean.z; mean.z += d * rc; m2.z += d * (v.z - mean.z);
+            d = v.w - mean.w; mean.w += d * rc; m2.w += d * (v.w - mean.w);
+        }
+    }
+    pm[w][lane] = mean;
+    pq[w][lane] = m2;
+    __syncthreads();
+    if (w != 0 || n >= N) return;
+    // Chan's merge of (count, mean, M2) partials, fixed order 0,1,2,3
+    float na = (float)((C + 3) / 4);                 // channels seen by wave 0
+    for (int k = 1; k < 4; ++k) {
+        const int ck = (C - k + 3) / 4;              // channels k, k+4, ... < C
+        if (ck <= 0) continue;
+        const float nb = (float)ck, nt = na + nb;
+        const float4 mb = pm[k][lane], qb = pq[k][lane];
+        const float f = nb / nt, g2 = na * nb / nt;
         float d;
-        d = v.x - mean.x; mean.x += d * rc; m2.x += d * (v.x - mean.x);
-        d = v.y - mean.y; mean.y += d * rc; m2.y += d * (v.y - mean.y);
-        d = v.z - mean.z; mean.z += d * rc; m2.z += d * (v.z - mean.z);
-        d = v.w - mean.w; mean.w += d * rc; m2.w += d * (v.w - mean.w);
+        d = mb.x - mean.x; mean.x += d * f; m2.x += qb.x + d * d * g2;
+        d = mb.y - mean.y; mean.y += d * f; m2.y += qb.y + d * d * g2;
+        d = mb.z - mean.z; mean.z += d * f; m2.z += qb.z + d * d * g2;
+        d = mb.w - mean.w; mean.w += d * f; m2.w += qb.w + d * d * g2;
+        na = nt;
     }
     const float inv = 1.0f / (float)C;
     float4 rstd;
@@ -38,7 +63,7 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
 extern "C" int irm_ln_stats_f32(const float* x, long x_bs, float* stats, int B, int C, int N, float eps,
                                 hipStream_t stream) {
     if (!x || !stats || B <= 0 || C <= 0 || N <= 0 || B > 65535) return IRM_EINVAL;
-    dim3 grid(((N + 3) / 4 + 255) / 256, B);
+    dim3 grid(((N + 3) / 4 + 63) / 64, B);
     const bool vec = !(N & 3) && !(x_bs & 3) && irm_aligned16(x) && irm_aligned16(stats);
     if (vec) hipLaunchKernelGGL(ln_stats_kernel<true>, grid, dim3(256), 0, stream, x, x_bs, stats, C, N, eps);
     else hipLaunchKernelGGL(ln_stats_kernel<false>, grid, dim3(256), 0, stream, x, x_bs, stats, C, N, eps);

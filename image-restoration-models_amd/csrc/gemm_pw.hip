@@ -34,7 +34,68 @@ struct GemmArgs {
     int M, K, N;
     int mtiles, ksteps;           // ceil(M/16), 4*ceil(K/16)
     int ln_mode, act;
+    float* stats_out;             // optional [B][2][N]: LayerNorm statistics of Y over its M channels
+    float eps;                    // (single-pass launches only: every output channel lives in one workgroup)
 };
+
+
+// LayerNorm statistics of the finished output tile straight from the accumulators: lane (r, g)
+// holds pixels pix..pix+3 of channels 16 c + r, so a channel reduction is CT in-lane adds plus
+// a 16-lane butterfly.  Two passes (mean, then centred squares) in registers.
+template <int CT>
+__device__ __forceinline__ void irm_stats_from_acc(const f32x4 (&acc)[2][CT], int mt0, int M, int N, int r,
+                                                   const int (&pixs)[2], float* st, float eps) {
+    float sum[2][4], sq[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sum[p][e] = 0.f; sq[p][e] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const bool ok = (mt0 + c) * 16 + r < M;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum[p][e] += ok ? acc[p][c][e] : 0.f;
+    }
+    const float inv = 1.0f / (float)M;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sum[p][e] += __shfl_xor(sum[p][e], o);
+            sum[p][e] *= inv;                                   // mean
+        }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const bool ok = (mt0 + c) * 16 + r < M;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = acc[p][c][e] - sum[p][e];
+                sq[p][e] += ok ? d * d : 0.f;
+            }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sq[p][e] += __shfl_xor(sq[p][e], o);
+            sq[p][e] = 1.0f / sqrtf(sq[p][e] * inv + eps);      // rstd
+        }
+        if (r == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (pixs[p] + e < N) {
+                    st[pixs[p] + e] = sum[p][e];
+                    st[N + pixs[p] + e] = sq[p][e];
+                }
+        }
+    }
+}
 
 template <int PT, int CT, bool VEC>
 __global__ __launch_bounds__(256) void gemm_pw_kernel(GemmArgs a) {
@@ -163,46 +224,49 @@ __global__ __launch_bounds__(256) void gemm_pw_kernel(GemmArgs a) {
         }
 
         // epilogue: lane holds pixels pix..pix+3 of channel co for every (p, c)
+        int pixs[PT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) pixs[p] = n0 + wave * 16 * PT + p * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int co = (mt0 + c) * 16 + (lane & 15);
+            const bool row_ok = c < nct && co < a.M;
+            const float bv = (a.bias && row_ok) ? a.bias[co] : 0.0f;
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                float4 v = make_float4(acc[p][c][0] + bv, acc[p][c][1] + bv, acc[p][c][2] + bv, acc[p][c][3] + bv);
+                if (a.act != IRM_ACT_NONE) {
+                    v.x = irm_act(v.x, a.act); v.y = irm_act(v.y, a.act);
+                    v.z = irm_act(v.z, a.act); v.w = irm_act(v.w, a.act);
+                }
+                if (R && row_ok && pixs[p] < a.N) {
+                    const float4 q = irm_ld4<VEC>(R + (long)co * a.N, pixs[p], a.N);
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                }
+                acc[p][c] = (f32x4){v.x, v.y, v.z, v.w};
+            }
+        }
+        if (PT == 2) {
+            if (a.stats_out) {
+                const int px2[2] = {pixs[0], pixs[PT - 1]};
+                irm_stats_from_acc<CT>(reinterpret_cast<const f32x4(&)[2][CT]>(acc), mt0, a.M, a.N, lane & 15, px2,
+                                       a.stats_out + (long)b * 2 * a.N, a.eps);
+            }
+        }
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             const int co = (mt0 + c) * 16 + (lane & 15);
             if (c < nct && co < a.M) {
-                const float bv = a.bias ? a.bias[co] : 0.0f;
 #pragma unroll
-                for (int p = 0; p < PT; ++p) {
-                    const int pix = n0 + wave * 16 * PT + p * 16 + (lane >> 4) * 4;
-                    if (pix < a.N) {
-                        float4 v = make_float4(acc[p][c][0] + bv, acc[p][c][1] + bv, acc[p][c][2] + bv,
-                                               acc[p][c][3] + bv);
-                        if (a.act != IRM_ACT_NONE) {
-                            v.x = irm_act(v.x, a.act); v.y = irm_act(v.y, a.act);
-                            v.z = irm_act(v.z, a.act); v.w = irm_act(v.w, a.act);
-                        }
-                        const long off = (long)co * a.N;
-                        if (R) {
-                            const float4 r = irm_ld4<VEC>(R + off, pix, a.N);
-                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                        }
-                        irm_st4<VEC>(Y + off, pix, a.N, v);
-                    }
-                }
+                for (int p = 0; p < PT; ++p)
+                    if (pixs[p] < a.N)
+                        irm_st4<VEC>(Y + (long)co * a.N, pixs[p], a.N,
+                                     make_float4(acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]));
             }
         }
     }
 }
 
-// ---------------------------------------------------------------------------
-// Fast path (every operand row 16-byte aligned, N % 4 == 0): the same GEMM as an
-// NS-deep LDS-DMA ring.  X rows (16 channels x 128 pixels = 8 KiB) and the
-// packed weights of the pass (CT KiB) are copied global -> LDS by
-// global_load_lds_dwordx4 (no VGPR staging), NS-1 stages stay in flight across
-// the per-stage barrier behind a counted s_waitcnt vmcnt(N), and the pipeline
-// runs on over pass boundaries, so the epilogue stores of one pass overlap the
-// loads of the next.  The LayerNorm prologue moves to the LDS -> register read:
-// a = ((x - mu) * rstd) * w[k] + b[k] costs 2 FMAs per A fragment, 18 MFMAs apart.
-// Out-of-range rows / columns / tiles are handled by clamping the source
-// address (their products meet zero-padded weights or are never stored), so
-// the DMA needs no masking and LDS never holds uninitialised bits.
 __device__ __attribute__((noinline)) float irm_act_slow(float v, int act) { return irm_act(v, act); }
 
 template <int N>
@@ -372,6 +436,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
                         acc[p][c][2] += rv[p][c].z; acc[p][c][3] += rv[p][c].w;
                     }
             }
+            if (a.stats_out) irm_stats_from_acc<CT>(acc, mt0, a.M, a.N, r, pixs, a.stats_out + (long)b * 2 * a.N, a.eps);
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 const int co = (mt0 + c) * 16 + r;
@@ -431,7 +496,7 @@ static bool irm_force_generic() {
 extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long x_bs, float* y, long y_bs,
                                const float* res, long r_bs, const float* bias, const float* stats,
                                const float* lnw, const float* lnb, int ln_mode, int act, int B, int M, int K,
-                               int N, int ct, int ygroups, hipStream_t stream) {
+                               int N, int ct, int ygroups, float* stats_out, float eps, hipStream_t stream) {
     if (!wp || !x || !y || B <= 0 || M <= 0 || K <= 0 || N <= 0) return IRM_EINVAL;
     if (ln_mode != IRM_LN_NONE && (!stats || !lnw || (ln_mode == IRM_LN_WITHBIAS && !lnb))) return IRM_EINVAL;
     if (ln_mode < 0 || ln_mode > 2 || act < 0 || act > 3) return IRM_EINVAL;
@@ -443,7 +508,9 @@ extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long 
     a.Wp = wp; a.w_bs = w_bs; a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.R = res; a.r_bs = r_bs;
     a.bias = bias; a.stats = stats; a.lnw = lnw; a.lnb = lnb;
     a.M = M; a.K = K; a.N = N; a.mtiles = (M + 15) / 16; a.ksteps = 4 * ((K + 15) / 16);
-    a.ln_mode = ln_mode; a.act = act;
+    a.ln_mode = ln_mode; a.act = act; a.stats_out = stats_out; a.eps = eps;
+    // fused output statistics need every output channel in one workgroup pass
+    if (stats_out && (ct <= 0 || a.mtiles > ct)) return IRM_EINVAL;
     const int nchunks = (a.mtiles + (ct > 0 ? ct : 1) - 1) / (ct > 0 ? ct : 1);
     if (ygroups <= 0) ygroups = 1;
     if (ygroups > nchunks) ygroups = nchunks;

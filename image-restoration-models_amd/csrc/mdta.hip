@@ -188,45 +188,54 @@ __global__ __launch_bounds__(256) void mdta_finalize_kernel(FinArgs a) {
     const int c = a.C / a.heads;
     const int head = blockIdx.x, b = blockIdx.y;
     const int rec = c * c + 2 * c;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* G = sm;                 // [c][c], overwritten by A
     float* nrm = sm + c * c;       // [2c] squared norms of q rows, k rows
     const float* p = a.gsum + ((long)b * a.heads + head) * rec;
     for (int e = threadIdx.x; e < rec; e += 256) sm[e] = p[e];
     __syncthreads();
     const float temp = a.temperature[head];
-    for (int i = threadIdx.x; i < c; i += 256) {
+    // softmax: one wave per row, lanes over the columns
+    for (int i = wave; i < c; i += 4) {
         const float qi = fmaxf(sqrtf(nrm[i]), 1e-12f);
         float m = -INFINITY;
-        for (int j = 0; j < c; ++j) {
+        for (int j = lane; j < c; j += 64) {
             const float kj = fmaxf(sqrtf(nrm[c + j]), 1e-12f);
             const float l = G[i * c + j] / (qi * kj) * temp;
             G[i * c + j] = l;
             m = fmaxf(m, l);
         }
-        float s = 0.0f;
-        for (int j = 0; j < c; ++j) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float ssum = 0.0f;
+        for (int j = lane; j < c; j += 64) {
             const float e = expf(G[i * c + j] - m);
             G[i * c + j] = e;
-            s += e;
+            ssum += e;
         }
-        const float inv = 1.0f / s;
-        for (int j = 0; j < c; ++j) G[i * c + j] *= inv;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);
+        const float inv = 1.0f / ssum;
+        for (int j = lane; j < c; j += 64) G[i * c + j] *= inv;
     }
     __syncthreads();
-    if (a.attn) {
+    if (a.attn && blockIdx.z == 0) {
         float* o = a.attn + ((long)b * a.heads + head) * c * c;
         for (int e = threadIdx.x; e < c * c; e += 256) o[e] = G[e];
     }
+    // fold with project_out; the output rows are split over gridDim.z workgroups
     const int mtiles = (a.C + 15) / 16;
     float* mf = a.mfold + (long)b * mtiles * a.ksteps * 64;
-    for (int e = threadIdx.x; e < a.C * c; e += 256) {
+    const int rows_per = (a.C + gridDim.z - 1) / gridDim.z;
+    const int co0 = blockIdx.z * rows_per, co1 = min(co0 + rows_per, a.C);
+    for (int e = co0 * c + threadIdx.x; e < co1 * c; e += 256) {
         const int co = e / c, j = e % c;
         const float* wrow = a.wout + (long)co * a.C + head * c;
-        float s = 0.0f;
-        for (int i = 0; i < c; ++i) s += wrow[i] * G[i * c + j];
+        float acc = 0.0f;
+        for (int i = 0; i < c; ++i) acc += wrow[i] * G[i * c + j];
         const int kcol = head * c + j;
-        const int lane = (co & 15) + 16 * (kcol & 3);
-        mf[((long)(co >> 4) * a.ksteps + (kcol >> 2)) * 64 + lane] = s;
+        const int ln = (co & 15) + 16 * (kcol & 3);
+        mf[((long)(co >> 4) * a.ksteps + (kcol >> 2)) * 64 + ln] = acc;
     }
 }
 
@@ -247,6 +256,6 @@ extern "C" int irm_mdta_finalize_f32(const float* part, float* gsum, const float
     // padded rows/cols of the packed matrix stay zero: the caller clears mfold once at allocation
     // (C is a multiple of 16 at every Restormer level, so normally there is no padding at all)
     FinArgs a{gsum, temperature, wout, mfold, attn, C, heads, 4 * ((C + 15) / 16)};
-    hipLaunchKernelGGL(mdta_finalize_kernel, dim3(heads, B), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(mdta_finalize_kernel, dim3(heads, B, 8), dim3(256), lds, stream, a);
     return irm_launch_status();
 }

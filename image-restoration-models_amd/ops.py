@@ -21,16 +21,17 @@ class KernelTimer:
     logs the call's algorithmic FLOPs and compulsory bytes (inputs read once,
     outputs written once, fp32).  ``summary()`` synchronises and aggregates."""
 
-    def __init__(self):
+    def __init__(self, detail=False):
         self.records = []          # (kernel, start_event, end_event, flops, bytes)
+        self.detail = detail       # key the summary by kernel + shape tag
 
-    def launch(self, kernel, fn, flops=0.0, nbytes=0.0):
+    def launch(self, kernel, fn, flops=0.0, nbytes=0.0, tag=""):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        self.records.append((kernel, e0, e1, float(flops), float(nbytes)))
+        self.records.append((kernel + (" " + tag if self.detail and tag else ""), e0, e1, float(flops), float(nbytes)))
 
     def summary(self):
         torch.cuda.synchronize()
@@ -48,11 +49,11 @@ class KernelTimer:
 TIMER: KernelTimer | None = None
 
 
-def _launch(kernel, flops, nbytes, name, *args):
+def _launch(kernel, flops, nbytes, name, *args, tag=""):
     if TIMER is None:
         _hip.call(name, *args)
     else:
-        TIMER.launch(kernel, lambda: _hip.call(name, *args), flops, nbytes)
+        TIMER.launch(kernel, lambda: _hip.call(name, *args), flops, nbytes, tag)
 
 
 def _chk(t: torch.Tensor, name: str):
@@ -80,13 +81,14 @@ def ln_stats(x: torch.Tensor, stats: torch.Tensor, eps: float = 1e-5):
     assert stats.numel() >= B * 2 * H * W and stats.is_contiguous()
     N = H * W
     _launch("ln_stats", 5.0 * B * C * N, 4.0 * B * N * (C + 2), "irm_ln_stats_f32", _hip.ptr(x), _bs(x),
-            _hip.ptr(stats), B, C, N, float(eps))
+            _hip.ptr(stats), B, C, N, float(eps), tag=f"C{C} N{N} B{B}")
 
 
 def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, *, res=None, bias=None,
             stats=None, lnw=None, lnb=None, ln_mode=LN_NONE, act=ACT_NONE, w_bs: int = 0, ct: int | None = None,
-            ygroups: int | None = None):
-    """y = act(W @ LN(x) + bias) (+ res); wp from _hip.pack_gemm_weight."""
+            ygroups: int | None = None, stats_out=None, eps: float = 1e-5):
+    """y = act(W @ LN(x) + bias) (+ res); wp from _hip.pack_gemm_weight.
+    stats_out: optional [B,2,N] buffer receiving the LayerNorm statistics of y (needs M <= 16*ct)."""
     _chk(x, "x"), _chk(y, "y")
     B, _, H, W = x.shape
     N = H * W
@@ -100,10 +102,15 @@ def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, 
         nchunks = -(-mt // ct)
         blocks = -(-N // 128) * B
         ygroups = max(1, min(nchunks, -(-target_blocks() // blocks)))
-    nbytes = 4.0 * B * N * (K + M + (M if res is not None else 0) + (2 if stats is not None else 0))
+    if stats_out is not None:
+        assert mt <= ct, "fused output statistics need all output channels in one pass"
+        ygroups = 1
+    nbytes = 4.0 * B * N * (K + M + (M if res is not None else 0) + (2 if stats is not None else 0)
+                            + (2 if stats_out is not None else 0))
     _launch("gemm1x1", 2.0 * B * M * K * N, nbytes, "irm_gemm1x1_f32", _hip.ptr(wp), int(w_bs), _hip.ptr(x), _bs(x),
             _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), _hip.ptr(stats), _hip.ptr(lnw),
-            _hip.ptr(lnb), int(ln_mode), int(act), B, M, K, N, ct, ygroups)
+            _hip.ptr(lnb), int(ln_mode), int(act), B, M, K, N, ct, ygroups, _hip.ptr(stats_out), float(eps),
+            tag=f"M{M} K{K} N{N} B{B} ln{int(ln_mode)} res{int(res is not None)} ct{ct} yg{ygroups}")
 
 
 def dwconv3x3(x, w9, y, *, bias=None, act=ACT_NONE):
@@ -111,7 +118,7 @@ def dwconv3x3(x, w9, y, *, bias=None, act=ACT_NONE):
     _chk(x, "x"), _chk(y, "y")
     B, C, H, W = x.shape
     _launch("dwconv3x3", 18.0 * B * C * H * W, 8.0 * B * C * H * W, "irm_dwconv3x3_f32", _hip.ptr(x), _bs(x),
-            _hip.ptr(w9), _hip.ptr(bias), _hip.ptr(y), _bs(y), B, C, H, W, int(act))
+            _hip.ptr(w9), _hip.ptr(bias), _hip.ptr(y), _bs(y), B, C, H, W, int(act), tag=f"C{C} {H}x{W} B{B}")
 
 
 def dwconv3x3_gate(x, w9, y, *, bias=None):
@@ -119,7 +126,8 @@ def dwconv3x3_gate(x, w9, y, *, bias=None):
     _chk(x, "x"), _chk(y, "y")
     B, C2, H, W = x.shape
     _launch("dwconv3x3_gate", 18.0 * B * C2 * H * W, 4.0 * B * (C2 + C2 // 2) * H * W, "irm_dwconv3x3_gate_f32",
-            _hip.ptr(x), _bs(x), _hip.ptr(w9), _hip.ptr(bias), _hip.ptr(y), _bs(y), B, C2 // 2, H, W)
+            _hip.ptr(x), _bs(x), _hip.ptr(w9), _hip.ptr(bias), _hip.ptr(y), _bs(y), B, C2 // 2, H, W,
+            tag=f"hid{C2 // 2} {H}x{W} B{B}")
 
 
 def mdta_plan(B: int, C: int, heads: int, N: int):
@@ -141,10 +149,16 @@ def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, att
     assert part.numel() >= B * heads * nchunk * rec and gsum.numel() >= B * heads * rec
     c = C // heads
     _launch("mdta_gram", 2.0 * B * heads * c * c * N, 8.0 * B * C * N, "irm_mdta_gram_f32", _hip.ptr(qkv), _bs(qkv),
-            _hip.ptr(part), B, C, heads, N, chunk)
+            _hip.ptr(part), B, C, heads, N, chunk, tag=f"C{C} h{heads} N{N} B{B} chunk{chunk}")
     _launch("mdta_finalize", 2.0 * B * C * C * c, 4.0 * B * (heads * nchunk * rec + C * C), "irm_mdta_finalize_f32",
             _hip.ptr(part), _hip.ptr(gsum), _hip.ptr(temperature), _hip.ptr(wout), _hip.ptr(mfold), _hip.ptr(attn),
-            B, C, heads, nchunk)
+            B, C, heads, nchunk, tag=f"C{C} h{heads} nchunk{nchunk} B{B}")
+
+
+def can_fuse_stats(M: int) -> bool:
+    """True if a GEMM with M output channels can emit the next LayerNorm's statistics (single pass)."""
+    mt = (M + 15) // 16
+    return mt <= _hip.choose_ct(mt)
 
 
 def mfold_numel(C: int) -> int:
@@ -167,4 +181,4 @@ def conv3x3(wp, x, y, ci: int, co: int, *, bias=None, relu1=False, res=None, res
     nbytes = 4.0 * B * H * W * (ci + co + (co if res is not None else 0))
     _launch("conv3x3", 18.0 * B * ci * co * H * W, nbytes, "irm_conv3x3_f32", _hip.ptr(wp), _hip.ptr(x), _bs(x),
             _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), B, ci, co, H, W, int(relu1), int(res_mode),
-            int(relu2), int(store_mode), ct, ygroups)
+            int(relu2), int(store_mode), ct, ygroups, tag=f"ci{ci} co{co} {H}x{W} B{B} ct{ct} yg{ygroups} st{store_mode}")

@@ -136,7 +136,7 @@ class Restormer(nn.Module):
         self.output = nn.Conv2d(d2, out_channels, 3, padding=1, bias=bias)
         self._packed = None
         self._packed_key = None
-        self._ws = {}
+        self._ws_by_stream = {}
         #: tiles of one image processed per forward by the device tiler (utils.tiled_forward_device)
         self.max_tiles_per_batch = 9
 
@@ -191,31 +191,45 @@ class Restormer(nn.Module):
         return pk
 
     # ------------------------------------------------------------------ workspace
+    @property
+    def _ws(self):
+        """Workspace of the current stream (concurrent forwards on different streams must not share)."""
+        return self._ws_by_stream.setdefault(torch.cuda.current_stream().cuda_stream if torch.cuda.is_available()
+                                             else 0, {})
+
     def _buf(self, name, numel, device):
-        t = self._ws.get(name)
+        ws = self._ws
+        t = ws.get(name)
         if t is None or t.numel() < numel or t.device != device:
             t = torch.empty(int(numel), dtype=torch.float32, device=device)
-            self._ws[name] = t
+            ws[name] = t
         return t[:numel]
 
     def release_workspace(self):
-        self._ws.clear()
+        self._ws_by_stream.clear()
 
     # ------------------------------------------------------------------ kernels
-    def _block(self, blk: TransformerBlock, w: dict, x: torch.Tensor):
-        """One TransformerBlock, in place on x (a [B][C][H][W] view, channel/pixel axes dense)."""
+    def _block(self, blk: TransformerBlock, w: dict, x: torch.Tensor, have_stats: bool = False,
+               want_stats: bool = True) -> bool:
+        """One TransformerBlock, in place on x (a [B][C][H][W] view, channel/pixel axes dense).
+
+        have_stats: the "stats" workspace already holds the LayerNorm statistics of x (written by the
+        epilogue of the GEMM that produced x).  Returns True if it left the statistics of its output
+        there for the next block (fused into project_out's epilogue; needs C <= 144)."""
         B, C, H, W = x.shape
         N = H * W
         dev = x.device
         heads = blk.attn.num_heads
         hid = blk.ffn.hidden
+        fuse = ops.can_fuse_stats(C)
         stats = self._buf("stats", B * 2 * N, dev)
         big_a = self._buf("scratch_a", B * max(3 * C, 2 * hid) * N, dev)
         big_b = self._buf("scratch_b", B * max(3 * C, hid) * N, dev)
         qkv = big_a[:B * 3 * C * N].view(B, 3 * C, H, W)
         qkv2 = big_b[:B * 3 * C * N].view(B, 3 * C, H, W)
         # --- attention branch: x += project_out(softmax(q k^T) v)   (restormer.py:111-132, 147)
-        ops.ln_stats(x, stats)
+        if not have_stats:
+            ops.ln_stats(x, stats)
         ops.gemm1x1(w["qkv"], x, qkv, 3 * C, C, bias=w["qkv_b"], stats=stats, lnw=w["n1w"], lnb=w["n1b"],
                     ln_mode=blk.norm1.mode)
         ops.dwconv3x3(qkv, w["qkv_dw"], qkv2, bias=w["qkv_dw_b"])
@@ -223,20 +237,25 @@ class Restormer(nn.Module):
         part = self._buf("gram_part", B * heads * nchunk * rec, dev)
         gsum = self._buf("gram_sum", B * heads * rec, dev)
         mfold_n = ops.mfold_numel(C)
-        mfold = self._ws.get(("mfold", C, B))
+        ws = self._ws
+        mfold = ws.get(("mfold", C, B))
         if mfold is None or mfold.device != dev:
             mfold = torch.zeros(B * mfold_n, dtype=torch.float32, device=dev)
-            self._ws[("mfold", C, B)] = mfold
+            ws[("mfold", C, B)] = mfold
         ops.mdta_fold(qkv2, part, gsum, w["temp"], w["wout"], mfold, C, heads)
-        ops.gemm1x1(mfold, qkv2[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n)
+        ops.gemm1x1(mfold, qkv2[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n,
+                    stats_out=stats if fuse else None)
         # --- feed-forward branch: x += project_out(gelu(dw(h1)) * dw(h2))   (restormer.py:88-93, 148)
         h = big_a[:B * 2 * hid * N].view(B, 2 * hid, H, W)
         g = big_b[:B * hid * N].view(B, hid, H, W)
-        ops.ln_stats(x, stats)
+        if not fuse:
+            ops.ln_stats(x, stats)
         ops.gemm1x1(w["pin"], x, h, 2 * hid, C, bias=w["pin_b"], stats=stats, lnw=w["n2w"], lnb=w["n2b"],
                     ln_mode=blk.norm2.mode)
         ops.dwconv3x3_gate(h, w["ffn_dw"], g, bias=w["ffn_dw_b"])
-        ops.gemm1x1(w["pout"], g, x, C, hid, res=x, bias=w["pout_b"])
+        emit = fuse and want_stats
+        ops.gemm1x1(w["pout"], g, x, C, hid, res=x, bias=w["pout_b"], stats_out=stats if emit else None)
+        return emit
 
     @staticmethod
     def _c3(wp, x, y, ci, co, h, w, **kw):
@@ -247,9 +266,11 @@ class Restormer(nn.Module):
     def _g1(wp, x, y, m, k, **kw):
         ops.gemm1x1(wp, x, y, m, k, **kw)
 
-    def _run_stage(self, name, pk, x):
-        for i, blk in enumerate(getattr(self, name)):
-            self._block(blk, pk[f"{name}.{i}"], x)
+    def _run_stage(self, name, pk, x, have_stats=False):
+        blocks = getattr(self, name)
+        for i, blk in enumerate(blocks):
+            have_stats = self._block(blk, pk[f"{name}.{i}"], x, have_stats, want_stats=i + 1 < len(blocks))
+        return have_stats
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -299,7 +320,7 @@ class Restormer(nn.Module):
         self._run_stage("decoder_level2", pk, dec2)
         self._c3(pk["up2_1"], dec2, cat1[:, :d1], d2, d2 * 2, H2, W2, store_mode=2)
         self._run_stage("decoder_level1", pk, cat1)
-        self._run_stage("refinement", pk, cat1)
+        self._run_stage("refinement", pk, cat1)          # (first block recomputes its statistics)
 
         out = torch.empty(B, self.out_channels, H, W, dtype=torch.float32, device=dev)
         if self.dual_pixel_task:

@@ -181,6 +181,14 @@ def tile_origins(extent: int, patch: int, overlap: int) -> list:
 
 
 _WINDOW_CACHE: dict = {}
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device, index: int):
+    key = (str(device), index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
 
 
 def _window_on(device, ps: int) -> torch.Tensor:
@@ -224,12 +232,37 @@ def tiled_forward_device(model: Module, img_dev: torch.Tensor, patch_size, patch
               _hip.ptr(tiles), h, w, c, th, tw, ph, pw, T, 0.0, 1.0)
     c_out = min(3, c)
     pred = None
-    for i in range(0, T, max_batch):
-        o = model(tiles[i:i + max_batch])
-        if pred is None:
-            pred = o if o.shape[0] == T else torch.empty(T, *o.shape[1:], dtype=torch.float32, device=dev)
-        if pred is not o:
+    nstreams = min(int(getattr(model, "num_streams", 1)), T)
+    if nstreams > 1:
+        # independent tile groups on separate HIP streams: one group's HBM-bound kernels overlap the
+        # other's MFMA-bound GEMMs; the groups join before the blend
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        per = -(-T // nstreams)
+        done, outs = [], []
+        for gi, i in enumerate(range(0, T, per)):
+            st = _side_stream(dev, gi)
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                o = model(tiles[i:i + per])
+                outs.append((i, o))
+                ev = torch.cuda.Event()
+                ev.record(st)
+                done.append(ev)
+        for ev in done:
+            main.wait_event(ev)
+        pred = torch.empty(T, *outs[0][1].shape[1:], dtype=torch.float32, device=dev)
+        for i, o in outs:
             pred[i:i + o.shape[0]] = o
+            o.record_stream(main)
+    else:
+        for i in range(0, T, max_batch):
+            o = model(tiles[i:i + max_batch])
+            if pred is None:
+                pred = o if o.shape[0] == T else torch.empty(T, *o.shape[1:], dtype=torch.float32, device=dev)
+            if pred is not o:
+                pred[i:i + o.shape[0]] = o
     if keep_tiles is not None:
         keep_tiles.append(pred[:, :c_out, :th, :tw].clone())
     out = torch.empty(h, w, c_out, dtype=img_dev.dtype, device=dev)

@@ -50,7 +50,7 @@ int irm_version(void);
  * stats[b][1][n] = 1/sqrt(biased_var + eps).
  * Replaces the statistics part of BiasFree_/WithBias_LayerNorm
  * (src/restormer/restormer.py:25-70); the normalisation itself is applied as
- * the prologue of irm_gemm1x1_f32.  N % 4 == 0. */
+ * the prologue of irm_gemm1x1_f32. */
 int irm_ln_stats_f32(const float* x, long x_bs, float* stats, int B, int C, int N, float eps,
                      irm_stream_t stream);
 
@@ -64,15 +64,19 @@ int irm_ln_stats_f32(const float* x, long x_bs, float* stats, int B, int C, int 
  * With w_bs != 0 each batch element has its own packed matrix (the folded
  * attention matrix from irm_mdta_finalize_f32).
  * ct: output-channel tiles per pass (3,4,6,8,9); ygroups: grid split of the
- * passes (>=1).  N % 4 == 0. */
+ * passes (>=1).  stats_out (optional, NULL to skip): [B][2][N] LayerNorm
+ * statistics (mean, 1/sqrt(var+eps)) of y over its M channels for the NEXT
+ * LayerNorm, produced in the epilogue; needs ceil(M/16) <= ct (one pass).
+ * Operands whose rows are 16-byte aligned (N % 4 == 0, aligned bases/strides)
+ * take the LDS-DMA ring kernel, anything else an exact scalar-path kernel. */
 int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long x_bs, float* y, long y_bs,
                     const float* res, long r_bs, const float* bias, const float* stats, const float* lnw,
                     const float* lnb, int ln_mode, int act, int B, int M, int K, int N, int ct, int ygroups,
-                    irm_stream_t stream);
+                    float* stats_out, float eps, irm_stream_t stream);
 
 /* Depth-wise 3x3 convolution, zero pad 1: y[b][c] = act(dw3x3(x[b][c]; w[c]) + bias[c]).
  * Replaces Attention.qkv_dwconv (restormer.py:106) and MaIR's conv2d+SiLU.
- * w: [C][9] (device), bias: [C] or NULL.  W % 4 == 0. */
+ * w: [C][9] (device), bias: [C] or NULL. */
 int irm_dwconv3x3_f32(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs, int B,
                       int C, int H, int W, int act, irm_stream_t stream);
 
@@ -85,7 +89,7 @@ int irm_dwconv3x3_gate_f32(const float* x, long x_bs, const float* w, const floa
 /* MDTA pass 1: per-chunk partial Gram matrices and squared norms.
  * qkv: [B][3C][N] (after qkv_dwconv; q rows [0,C), k rows [C,2C)).
  * part: workspace [B][heads][ceil(N/chunk)][c*c + 2c] floats, c = C/heads,
- * c % 16 == 0, chunk % 64 == 0, N % 4 == 0.
+ * c % 16 == 0, chunk % 64 == 0.
  * Replaces F.normalize + q @ k^T of Attention.forward (restormer.py:122-125);
  * the normalisation is applied to the Gram matrix afterwards. */
 int irm_mdta_gram_f32(const float* qkv, long bs, float* part, int B, int C, int heads, int N, int chunk,

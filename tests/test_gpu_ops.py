@@ -112,6 +112,30 @@ def test_gemm1x1(dev, M, K, H, W, B, ln, res, bias, act, ct, yg):
     assert torch.all(got[:, 0] == 7.0) and torch.all(got[:, 1 + M:] == 7.0)     # no stray writes
 
 
+@pytest.mark.parametrize("M,K,H,W,B,res", [(96, 255, 16, 24, 2, True), (48, 48, 8, 16, 1, True), (144, 96, 16, 16, 1, False),
+                                           (96, 96, 5, 7, 2, True), (40, 30, 8, 8, 1, True)])
+def test_gemm1x1_fused_output_statistics(dev, M, K, H, W, B, res):
+    """stats_out = LayerNorm statistics of the GEMM result (incl. residual) for the next LayerNorm."""
+    tag = f"fs{M}_{K}_{H}"
+    w = rnd(tag + "w", (M, K), -0.3, 0.3)
+    x = rnd(tag + "x", (B, K, H, W), -1.5, 2.0)
+    r = rnd(tag + "r", (B, M, H, W), -3, 3) if res else None
+    ref = torch.einsum("mk,bkhw->bmhw", w.double(), x.double()) + (r.double() if res else 0)
+    mean = ref.mean(1).reshape(B, -1)
+    rstd = 1.0 / torch.sqrt(ref.var(1, unbiased=False) + 1e-5).reshape(B, -1)
+    y = torch.empty(B, M, H, W, device=dev)
+    st = torch.full((B, 2, H * W), float("nan"), device=dev)
+    ops.gemm1x1(_hip.pack_gemm_weight(w).to(dev), x.to(dev), y, M, K, res=r.to(dev) if res else None, stats_out=st)
+    assert (y.cpu().double() - ref).abs().max() < TOL * max(1.0, float(ref.abs().max()))
+    s = st.cpu().double()
+    assert (s[:, 0] - mean).abs().max() < 1e-5 * max(1.0, float(mean.abs().max()))
+    assert ((s[:, 1] - rstd).abs() / rstd).max() < 1e-5
+    # and against the standalone statistics kernel on the same tensor
+    st2 = torch.empty(B, 2, H * W, device=dev)
+    ops.ln_stats(y, st2)
+    assert (st2 - st).abs().max() < 1e-5
+
+
 def test_gemm1x1_inplace_residual_and_per_batch_weights(dev):
     B, C, H, W = 3, 96, 8, 16
     x = rnd("ipx", (B, C, H, W))
