@@ -34,7 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import irm_amd  # noqa: E402,F401
-from irm_amd import ops, restormer, synth, utils  # noqa: E402
+from irm_amd import ops, parallel, restormer, synth, utils  # noqa: E402
 from irm_amd.configs import PATCH_CONFIG  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
@@ -128,16 +128,10 @@ def main():
     ops.TIMER = None
 
     # max over ranks, PSNR rows gathered once (tens of bytes per image)
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    rows = torch.tensor([[rank * args.steps + i, float(10 * np.log10(255.0 ** 2 / max(float(s.item()) / (H * W * C), 1e-12)))]
-                         for i, (_, s) in enumerate(results)], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        allrows = [torch.empty_like(rows) for _ in range(world)]
-        dist.all_gather(allrows, rows)
-        rows = torch.cat(allrows)
-    elapsed = float(el.item())
-    psnr = rows[:, 1].cpu().numpy()
+    rows = [(rank * args.steps + i, float(10 * np.log10(255.0 ** 2 / max(float(s.item()) / (H * W * C), 1e-12))))
+            for i, (_, s) in enumerate(results)]
+    elapsed, table = parallel.gather_results(elapsed, rows, dev)
+    psnr = table[:, 1].numpy()
 
     if rank == 0:
         out = {
