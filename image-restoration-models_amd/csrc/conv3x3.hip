@@ -17,6 +17,7 @@
 // weight of that tap:  Wp[tap][mtile][kstep][lane] =
 // W[16 mtile + (lane&15)][4 kstep + (lane>>4)][tap/3][tap%3].
 #include "irm_common.h"
+#include <stdlib.h>
 
 #define CV_TH 8
 #define CV_TW 32
@@ -206,6 +207,194 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fast path (W % 4 == 0, 16-byte aligned planes): the same implicit GEMM as an LDS-DMA ring, 4 input
+// channels (one MFMA k-step) per stage.  The halo tile is fetched as aligned 16-byte chunks covering
+// columns [tx0-4, tx0+36) (10 chunks x 10 rows x 4 channels, one contiguous LDS image with the same
+// 400-float plane stride), out-of-image chunks read a 16-byte zero page, and the 9 taps' packed weights
+// of the pass (9*CT*256 B) arrive by DMA as well.  NS-1 stages stay in flight behind a counted vmcnt;
+// the pipeline runs across output-channel passes.
+__device__ __attribute__((aligned(16))) float irm_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int N>
+__device__ __forceinline__ void cv_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int CT, int NS>
+__global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(ConvArgs a) {
+    constexpr int XU = 8;                          // 1 KiB units of the input image per stage (400 chunks + pad:
+                                                   // every wave issues the same number of DMA instructions)
+    constexpr int WCH = 9 * CT * 16;               // 16-byte chunks of weights per stage
+    constexpr int WU = (WCH + 63) / 64;            // 1 KiB units of weights per stage
+    constexpr int WL = (WU + 3) / 4;               // weight DMA instructions per wave per stage
+    constexpr int STG = (XU + WU) * 256;           // floats per stage
+    constexpr int LPS = 2 + WL;
+    static_assert((NS - 2) * LPS <= 63, "vmcnt field");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int b = blockIdx.z;
+    const int ty0 = (blockIdx.x / a.tiles_x) * CV_TH;
+    const int tx0 = (blockIdx.x % a.tiles_x) * CV_TW;
+    const float* X = a.X + (long)b * a.x_bs;
+    const long plane = (long)a.H * a.W;
+
+    // per-lane source geometry of the two input DMA instructions of this wave (fixed over stages)
+    long xoff[2];
+    int xch[2];
+    bool xok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = (wave * 2 + j) * 64 + lane;             // chunk id within the stage image
+        const int ch = q / 100, rem = q % 100, row = rem / 10, chunk = rem % 10;
+        const int gy = ty0 - 1 + row, gx = tx0 - 4 + chunk * 4;
+        xch[j] = ch;
+        xok[j] = q < 400 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        xoff[j] = (long)ch * plane + (long)gy * a.W + gx;
+    }
+
+    const int S = (a.Ci + 3) / 4;                             // stages = k-steps with real channels
+    const int nchunks = (a.mtiles + CT - 1) / CT;
+    const int my_chunks = (nchunks - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int TOT = my_chunks * S;
+
+    auto issue = [&](int it) {
+        const int ci = it / S, s = it - ci * S;
+        const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
+        float* xb = smem + (it % NS) * STG;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = xok[j] && s * 4 + xch[j] < a.Ci;
+            const float* src = ok ? X + (long)s * 4 * plane + xoff[j] : irm_zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(xb + (wave * 2 + j) * 256),
+                                                 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WL; ++i) {
+            const int u = min(wave + 4 * i, WU - 1);          // surplus instructions repeat the last unit
+            const int qq = u * 64 + lane;
+            const int pair = qq >> 4, tap = pair / CT, ct = pair - tap * CT;
+            const int mt = min(mt0 + ct, a.mtiles - 1);
+            const float* src = qq < WCH
+                ? a.Wp + (((long)tap * a.mtiles + mt) * a.ksteps + s) * 64 + (qq & 15) * 4 : irm_zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xb + (XU + u) * 256), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][CT];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int j = 0; j < NS - 1; ++j)
+        if (j < TOT) issue(j);
+
+    int s = 0, ci = 0;
+    for (int it = 0; it < TOT; ++it) {
+        const int rem = min(NS - 2, TOT - 1 - it);
+        if (rem >= 1 && NS >= 3) cv_wait_vmcnt<LPS>();
+        else cv_wait_vmcnt<0>();
+        asm volatile("s_barrier" ::: "memory");
+        if (it + NS - 1 < TOT) issue(it + NS - 1);
+
+        const float* xb = smem + (it % NS) * STG;
+        const float* wb = xb + XU * 256;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            float af[4], bf[CT];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                af[p] = xb[g * CV_PLANE + (wave * 2 + (p >> 1) + dy) * CV_TWP + (p & 1) * 16 + r + dx + 3];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) bf[c] = wb[(tap * CT + c) * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[p][c] = irm_mfma16(af[p], bf[c], acc[p][c]);
+        }
+
+        if (++s == S) {
+            const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
+            float* Y = a.Y + (long)b * a.y_bs;
+            const float* R = a.R ? a.R + (long)b * a.r_bs : nullptr;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int co = (mt0 + c) * 16 + r;
+                const bool row_ok = mt0 + c < a.mtiles && co < a.Co;
+                const float bv = (a.bias && row_ok) ? a.bias[co] : 0.0f;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int y = ty0 + wave * 2 + (p >> 1);
+                    const int x = tx0 + (p & 1) * 16 + g * 4;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[p][c][e] + bv;
+                        if (a.relu1) v[e] = fmaxf(v[e], 0.0f);
+                    }
+                    acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (!row_ok || y >= a.H || x >= a.W) continue;
+                    if (a.store_mode == 0) {
+                        const long off = (long)co * plane + (long)y * a.W + x;
+                        if (a.res_mode) {
+                            const float4 rr = *reinterpret_cast<const float4*>(R + off);
+                            const float rv[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = a.res_mode == 1 ? v[e] + rv[e] : rv[e] - v[e];
+                        }
+                        if (a.relu2) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                        }
+                        *reinterpret_cast<float4*>(Y + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else if (a.store_mode == 1) {
+                        const int oh = a.H >> 1, ow = a.W >> 1;
+                        const long op = (long)oh * ow;
+                        const int oc = co * 4 + (y & 1) * 2;
+                        const long o = (long)(y >> 1) * ow + (x >> 1);
+                        *reinterpret_cast<float2*>(Y + (long)oc * op + o) = make_float2(v[0], v[2]);
+                        *reinterpret_cast<float2*>(Y + (long)(oc + 1) * op + o) = make_float2(v[1], v[3]);
+                    } else {
+                        const int ow = a.W * 2;
+                        const long op = (long)a.H * 2 * ow;
+                        const int oc = co >> 2, i = (co >> 1) & 1, jx = co & 1;
+                        float* o = Y + (long)oc * op + (long)(2 * y + i) * ow + 2 * x + jx;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[2 * e] = v[e];
+                    }
+                }
+            }
+            s = 0;
+            ++ci;
+        }
+    }
+}
+
+template <int CT>
+static int launch_conv_ring(const ConvArgs& a, int B, int ygroups, hipStream_t stream) {
+    constexpr int NS = 3;
+    constexpr int WU = (9 * CT * 16 + 63) / 64;
+    const size_t lds = (size_t)NS * (8 + WU) * 1024;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ring_kernel<CT, NS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return IRM_ELAUNCH;
+        configured = true;
+    }
+    const int tiles_y = (a.H + CV_TH - 1) / CV_TH;
+    dim3 grid(a.tiles_x * tiles_y, ygroups, B);
+    hipLaunchKernelGGL((conv3x3_ring_kernel<CT, NS>), grid, dim3(256), lds, stream, a);
+    return irm_launch_status();
+}
+
 template <int CT>
 static int launch_conv(const ConvArgs& a, int B, int ygroups, hipStream_t stream) {
     const int tiles_y = (a.H + CV_TH - 1) / CV_TH;
@@ -235,6 +424,17 @@ extern "C" int irm_conv3x3_f32(const float* wp, const float* x, long x_bs, float
     const int nchunks = (a.mtiles + ct - 1) / ct;
     if (ygroups <= 0) ygroups = 1;
     if (ygroups > nchunks) ygroups = nchunks;
+    const bool fast = a.vec && !(x_bs & 3) && irm_aligned16(x) && irm_aligned16(wp) && !getenv("IRM_CONV_GENERIC");
+    if (fast) {
+        switch (ct) {
+            case 1: return launch_conv_ring<1>(a, B, ygroups, stream);
+            case 2: return launch_conv_ring<2>(a, B, ygroups, stream);
+            case 3: return launch_conv_ring<3>(a, B, ygroups, stream);
+            case 4: return launch_conv_ring<4>(a, B, ygroups, stream);
+            case 6: return launch_conv_ring<6>(a, B, ygroups, stream);
+            default: return IRM_EINVAL;
+        }
+    }
     switch (ct) {
         case 1: return launch_conv<1>(a, B, ygroups, stream);
         case 2: return launch_conv<2>(a, B, ygroups, stream);
