@@ -42,25 +42,25 @@ struct GemmArgs {
 // LayerNorm statistics of the finished output tile straight from the accumulators: lane (r, g)
 // holds pixels pix..pix+3 of channels 16 c + r, so a channel reduction is CT in-lane adds plus
 // a 16-lane butterfly.  Two passes (mean, then centred squares) in registers.
-template <int CT>
-__device__ __forceinline__ void irm_stats_from_acc(const f32x4 (&acc)[2][CT], int mt0, int M, int N, int r,
-                                                   const int (&pixs)[2], float* st, float eps) {
-    float sum[2][4], sq[2][4];
+template <int PT, int CT>
+__device__ __forceinline__ void irm_stats_from_acc(const f32x4 (&acc)[PT][CT], int mt0, int M, int N, int r,
+                                                   const int (&pixs)[PT], float* st, float eps) {
+    float sum[PT][4], sq[PT][4];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < PT; ++p)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sum[p][e] = 0.f; sq[p][e] = 0.f; }
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const bool ok = (mt0 + c) * 16 + r < M;
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < PT; ++p)
 #pragma unroll
             for (int e = 0; e < 4; ++e) sum[p][e] += ok ? acc[p][c][e] : 0.f;
     }
     const float inv = 1.0f / (float)M;
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < PT; ++p)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -71,7 +71,7 @@ __device__ __forceinline__ void irm_stats_from_acc(const f32x4 (&acc)[2][CT], in
     for (int c = 0; c < CT; ++c) {
         const bool ok = (mt0 + c) * 16 + r < M;
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < PT; ++p)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float d = acc[p][c][e] - sum[p][e];
@@ -79,7 +79,7 @@ __device__ __forceinline__ void irm_stats_from_acc(const f32x4 (&acc)[2][CT], in
             }
     }
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < PT; ++p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -246,13 +246,8 @@ __global__ __launch_bounds__(256) void gemm_pw_kernel(GemmArgs a) {
                 acc[p][c] = (f32x4){v.x, v.y, v.z, v.w};
             }
         }
-        if (PT == 2) {
-            if (a.stats_out) {
-                const int px2[2] = {pixs[0], pixs[PT - 1]};
-                irm_stats_from_acc<CT>(reinterpret_cast<const f32x4(&)[2][CT]>(acc), mt0, a.M, a.N, lane & 15, px2,
-                                       a.stats_out + (long)b * 2 * a.N, a.eps);
-            }
-        }
+        if (a.stats_out)
+            irm_stats_from_acc<PT, CT>(acc, mt0, a.M, a.N, lane & 15, pixs, a.stats_out + (long)b * 2 * a.N, a.eps);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             const int co = (mt0 + c) * 16 + (lane & 15);
@@ -274,13 +269,14 @@ __device__ __forceinline__ void irm_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int CT, int NS, int LN>
+template <int PT, int CT, int NS, int LN, bool RES>
 __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
-    constexpr int BN = 128, BK = 16;
+    constexpr int BN = 64 * PT, BK = 16;            // pixels per workgroup, channels per stage
+    constexpr int RPU = 256 / BN;                   // X rows per 1 KiB DMA instruction (PT 2: 2, PT 4: 1)
     constexpr int XS = BK * BN;                 // floats of X per stage
     constexpr int STG = XS + CT * 256;          // floats per stage
     constexpr int WL = (CT + 3) / 4;            // weight DMA instructions per wave per stage
-    constexpr int LPS = 2 + WL;                 // DMA instructions per wave per stage
+    constexpr int LPS = PT + WL;                // DMA instructions per wave per stage
     static_assert((NS - 2) * LPS <= 63, "vmcnt field");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -291,16 +287,18 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
     const float* X = a.X + (long)b * a.x_bs;
     const float* Wp = a.Wp + (long)b * a.w_bs;
     float* Y = a.Y + (long)b * a.y_bs;
-    const float* R = a.R ? a.R + (long)b * a.r_bs : nullptr;
+    const float* R = (RES && a.R) ? a.R + (long)b * a.r_bs : nullptr;
     const int KP = a.ksteps * 4;
     float* lnp = smem + NS * STG;               // [2][KP]: LN weight, LN bias (zero padded)
 
-    float rs[2] = {1.f, 1.f}, nmr[2] = {0.f, 0.f};
+    float rs[PT], nmr[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) { rs[p] = 1.f; nmr[p] = 0.f; }
     if (LN != IRM_LN_NONE) {
         const float* st = a.stats + (long)b * 2 * a.N;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int pix = min(n0 + wave * 32 + p * 16 + r, a.N - 1);
+        for (int p = 0; p < PT; ++p) {
+            const int pix = min(n0 + wave * 16 * PT + p * 16 + r, a.N - 1);
             const float m = st[pix], q = st[a.N + pix];
             rs[p] = q;
             nmr[p] = -m * q;
@@ -317,19 +315,19 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
     const int my_chunks = (nchunks - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
     const int TOT = my_chunks * S;
 
-    const int xrow = 4 * wave + (lane >> 5);
-    const int xcol = min(n0 + (lane & 31) * 4, a.N - 4);
+    const int xrow = wave * PT * RPU + (lane * 4) / BN;        // + j * RPU
+    const int xcol = min(n0 + (lane * 4) % BN, a.N - 4);
 
     auto issue = [&](int it) {
         const int ci = it / S, s = it - ci * S;
         const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
         float* xb = smem + (it % NS) * STG;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = min(s * BK + xrow + 2 * j, a.K - 1);
+        for (int j = 0; j < PT; ++j) {
+            const int k = min(s * BK + xrow + j * RPU, a.K - 1);
             const float* src = X + (long)k * a.N + xcol;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(xb + (4 * wave + 2 * j) * BN),
+                                             (__attribute__((address_space(3))) void*)(xb + (wave * PT + j) * 256),
                                              16, 0, 0);
         }
 #pragma unroll
@@ -342,17 +340,17 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
         }
     };
 
-    f32x4 acc[2][CT];
+    f32x4 acc[PT][CT];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < PT; ++p)
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int pixs[2];
+    int pixs[PT];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) pixs[p] = n0 + wave * 32 + p * 16 + g * 4;
+    for (int p = 0; p < PT; ++p) pixs[p] = n0 + wave * 16 * PT + p * 16 + g * 4;
     // residual / bias of the running pass: loaded (clamped addresses, back to back) during the
     // pass's first stage and first used in its epilogue, so their latency hides under the MFMAs
-    float4 rv[2][CT];
+    float4 rv[RES ? PT : 1][RES ? CT : 1];
     float bvs[CT];
 
 #pragma unroll
@@ -363,19 +361,19 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
     for (int it = 0; it < TOT; ++it) {
         // stage `it` has landed once at most `rem` younger stages are still in flight
         const int rem = min(NS - 2, TOT - 1 - it);
-        if (rem >= 2 && NS >= 4) irm_wait_vmcnt<2 * LPS>();
+        if (rem >= 2 && NS >= 4) irm_wait_vmcnt<(NS >= 4 ? 2 : 0) * LPS>();
         else if (rem == 1 && NS >= 3) irm_wait_vmcnt<LPS>();
         else irm_wait_vmcnt<0>();
         asm volatile("s_barrier" ::: "memory");
         if (it + NS - 1 < TOT) issue(it + NS - 1);
         if (s == 0) {
             const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
-            if (R) {
+            if (RES && R) {
 #pragma unroll
-                for (int c = 0; c < CT; ++c) {
+                for (int c = 0; c < (RES ? CT : 0); ++c) {
                     const long row = (long)min((mt0 + c) * 16 + r, a.M - 1) * a.N;
 #pragma unroll
-                    for (int p = 0; p < 2; ++p)
+                    for (int p = 0; p < PT; ++p)
                         rv[p][c] = *reinterpret_cast<const float4*>(R + row + min(pixs[p], a.N - 4));
                 }
             }
@@ -389,15 +387,15 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
         const float* wb = xb + XS;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            float af[2], bf[CT];
+            float af[PT], bf[CT];
             float wk = 1.f, bk = 0.f;
             if (LN != IRM_LN_NONE) {
                 wk = lnp[s * BK + kk * 4 + g];
                 if (LN == IRM_LN_WITHBIAS) bk = lnp[KP + s * BK + kk * 4 + g];
             }
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const float x = xb[(kk * 4 + g) * BN + wave * 32 + p * 16 + r];
+            for (int p = 0; p < PT; ++p) {
+                const float x = xb[(kk * 4 + g) * BN + wave * 16 * PT + p * 16 + r];
                 if (LN == IRM_LN_WITHBIAS) af[p] = fmaf(fmaf(x, rs[p], nmr[p]), wk, bk);
                 else if (LN == IRM_LN_BIASFREE) af[p] = x * rs[p] * wk;
                 else af[p] = x;
@@ -407,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) acc[p][c] = irm_mfma16(af[p], bf[c], acc[p][c]);
+                for (int p = 0; p < PT; ++p) acc[p][c] = irm_mfma16(af[p], bf[c], acc[p][c]);
         }
 
         if (++s == S) {
@@ -417,32 +415,32 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
 #pragma unroll
                 for (int c = 0; c < CT; ++c)
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) acc[p][c] += bvs[c];
+                    for (int p = 0; p < PT; ++p) acc[p][c] += bvs[c];
             }
             if (a.act != IRM_ACT_NONE) {
 #pragma unroll
                 for (int c = 0; c < CT; ++c)
 #pragma unroll
-                    for (int p = 0; p < 2; ++p)
+                    for (int p = 0; p < PT; ++p)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[p][c][e] = irm_act_slow(acc[p][c][e], a.act);
             }
-            if (R) {
+            if (RES && R) {
 #pragma unroll
-                for (int c = 0; c < CT; ++c)
+                for (int c = 0; c < (RES ? CT : 0); ++c)
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
+                    for (int p = 0; p < PT; ++p) {
                         acc[p][c][0] += rv[p][c].x; acc[p][c][1] += rv[p][c].y;
                         acc[p][c][2] += rv[p][c].z; acc[p][c][3] += rv[p][c].w;
                     }
             }
-            if (a.stats_out) irm_stats_from_acc<CT>(acc, mt0, a.M, a.N, r, pixs, a.stats_out + (long)b * 2 * a.N, a.eps);
+            if (a.stats_out) irm_stats_from_acc<PT, CT>(acc, mt0, a.M, a.N, r, pixs, a.stats_out + (long)b * 2 * a.N, a.eps);
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 const int co = (mt0 + c) * 16 + r;
                 const bool row_ok = mt0 + c < a.mtiles && co < a.M;
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
+                for (int p = 0; p < PT; ++p) {
                     if (row_ok && pixs[p] < a.N)
                         *reinterpret_cast<float4*>(Y + (long)co * a.N + pixs[p]) =
                             make_float4(acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]);
@@ -455,27 +453,40 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
     }
 }
 
-template <int CT, int LN>
+template <int PT, int CT, int LN, bool RES>
 static int launch_ring(const GemmArgs& a, int B, int ygroups, hipStream_t stream) {
-    constexpr int NS = 4;
-    const size_t lds = ((size_t)NS * (16 * 128 + CT * 256) + 2 * (size_t)a.ksteps * 4) * sizeof(float);
+    constexpr int NS = PT == 2 ? 4 : 3;
+    constexpr int BN = 64 * PT;
+    const size_t lds = ((size_t)NS * (16 * BN + CT * 256) + 2 * (size_t)a.ksteps * 4) * sizeof(float);
     static bool configured = false;              // per instantiation
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<CT, NS, LN>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<PT, CT, NS, LN, RES>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return IRM_ELAUNCH;
         configured = true;
     }
-    dim3 grid((a.N + 127) / 128, ygroups, B);
-    hipLaunchKernelGGL((gemm_ring_kernel<CT, NS, LN>), grid, dim3(256), lds, stream, a);
+    dim3 grid((a.N + BN - 1) / BN, ygroups, B);
+    hipLaunchKernelGGL((gemm_ring_kernel<PT, CT, NS, LN, RES>), grid, dim3(256), lds, stream, a);
     return irm_launch_status();
 }
 
+// instantiated combinations: 64-pixel waves (PT 4) only without a residual (the prefetched residual
+// doubles the accumulator-sized register block); LayerNorm prologue only without a residual (the
+// path never combines them)
 template <int CT>
-static int launch_ring_ln(const GemmArgs& a, int B, int ygroups, hipStream_t stream) {
-    if (a.ln_mode == IRM_LN_WITHBIAS) return launch_ring<CT, IRM_LN_WITHBIAS>(a, B, ygroups, stream);
-    if (a.ln_mode == IRM_LN_BIASFREE) return launch_ring<CT, IRM_LN_BIASFREE>(a, B, ygroups, stream);
-    return launch_ring<CT, IRM_LN_NONE>(a, B, ygroups, stream);
+static int launch_ring_any(const GemmArgs& a, int B, int ygroups, int pt, hipStream_t stream) {
+    if (a.R) {
+        if (a.ln_mode != IRM_LN_NONE) return IRM_EINVAL;
+        return launch_ring<2, CT, IRM_LN_NONE, true>(a, B, ygroups, stream);
+    }
+    if (pt == 4) {
+        if (a.ln_mode == IRM_LN_WITHBIAS) return launch_ring<4, CT, IRM_LN_WITHBIAS, false>(a, B, ygroups, stream);
+        if (a.ln_mode == IRM_LN_BIASFREE) return launch_ring<4, CT, IRM_LN_BIASFREE, false>(a, B, ygroups, stream);
+        return launch_ring<4, CT, IRM_LN_NONE, false>(a, B, ygroups, stream);
+    }
+    if (a.ln_mode == IRM_LN_WITHBIAS) return launch_ring<2, CT, IRM_LN_WITHBIAS, false>(a, B, ygroups, stream);
+    if (a.ln_mode == IRM_LN_BIASFREE) return launch_ring<2, CT, IRM_LN_BIASFREE, false>(a, B, ygroups, stream);
+    return launch_ring<2, CT, IRM_LN_NONE, false>(a, B, ygroups, stream);
 }
 
 template <int PT, int CT>
@@ -515,13 +526,17 @@ extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long 
     if (ygroups <= 0) ygroups = 1;
     if (ygroups > nchunks) ygroups = nchunks;
     if (B > 65535 || ygroups > 65535) return IRM_EINVAL;
-    if (vec && N >= 4 && !irm_force_generic()) {
+    if (vec && N >= 4 && !irm_force_generic() && !(res && ln_mode != IRM_LN_NONE)) {
+        // 64 pixels per wave (PT 4) doubles the MFMAs per barrier; it is used when the accumulators
+        // (+ the prefetched residual) still fit 2 waves per SIMD and the grid stays large
+        int pt = (!res && (long)B * ((N + 255) / 256) * ygroups >= 512) ? 4 : 2;
+        if (const char* e = getenv("IRM_GEMM_PT")) pt = atoi(e);
         switch (ct) {
-            case 3: return launch_ring_ln<3>(a, B, ygroups, stream);
-            case 4: return launch_ring_ln<4>(a, B, ygroups, stream);
-            case 6: return launch_ring_ln<6>(a, B, ygroups, stream);
-            case 8: return launch_ring_ln<8>(a, B, ygroups, stream);
-            case 9: return launch_ring_ln<9>(a, B, ygroups, stream);
+            case 3: return launch_ring_any<3>(a, B, ygroups, pt, stream);
+            case 4: return launch_ring_any<4>(a, B, ygroups, pt, stream);
+            case 6: return launch_ring_any<6>(a, B, ygroups, pt, stream);
+            case 8: return launch_ring_any<8>(a, B, ygroups, pt, stream);
+            case 9: return launch_ring_any<9>(a, B, ygroups, pt, stream);
             default: return IRM_EINVAL;
         }
     }

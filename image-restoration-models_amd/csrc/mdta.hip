@@ -20,7 +20,8 @@
 // positions and (k-step, k-slot) is legal as long as q and k use the same one,
 // so each lane loads 16-byte pieces straight from global memory: lane (r, g)
 // of load j reads row r, positions slab + 16 j + 4 g .. +3, and the 4 elements
-// feed 4 successive MFMAs.  No LDS, no barriers.
+// feed 4 successive MFMAs.  No LDS, no barriers; the next 32 positions are prefetched into a
+// second register set while the current ones are multiplied.
 #include "irm_common.h"
 
 struct GramArgs {
@@ -62,37 +63,47 @@ __global__ __launch_bounds__(256) void mdta_gram_kernel(GramArgs a) {
 
     const int nbeg = chunk_id * a.chunk;
     const int nend = min(nbeg + a.chunk, a.N);
-    for (int slab = nbeg; slab < nend; slab += 64) {
-        float4 qa[SB][4], ka[SB][4];
+    // 32 positions per step (2 x 16 bytes per lane and tile), operands of step i+1 are fetched while
+    // the MFMAs of step i run (two register sets, static indexing through the 2x unrolled body)
+    float4 qa[2][SB][2], ka[2][SB][2];
+    auto fetch = [&](int set, int slab) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
             const int n = slab + 16 * j + 4 * g;
-            const bool ok = n < nend;             // chunk starts are multiples of 64
+            const bool ok = n < nend;
 #pragma unroll
             for (int i = 0; i < SB; ++i) {
-                qa[i][j] = ok ? irm_ld4<VEC>(q + (long)i * 16 * a.N, n, nend) : make_float4(0.f, 0.f, 0.f, 0.f);
-                ka[i][j] = ok ? irm_ld4<VEC>(k + (long)i * 16 * a.N, n, nend) : make_float4(0.f, 0.f, 0.f, 0.f);
+                qa[set][i][j] = ok ? irm_ld4<VEC>(q + (long)i * 16 * a.N, n, nend) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ka[set][i][j] = ok ? irm_ld4<VEC>(k + (long)i * 16 * a.N, n, nend) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+    };
+    auto consume = [&](int set) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
             for (int i = 0; i < SB; ++i) {
-                nq[i] += qa[i][j].x * qa[i][j].x + qa[i][j].y * qa[i][j].y + qa[i][j].z * qa[i][j].z +
-                         qa[i][j].w * qa[i][j].w;
-                nk[i] += ka[i][j].x * ka[i][j].x + ka[i][j].y * ka[i][j].y + ka[i][j].z * ka[i][j].z +
-                         ka[i][j].w * ka[i][j].w;
+                const float4 x = qa[set][i][j], y = ka[set][i][j];
+                nq[i] += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+                nk[i] += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
             }
 #pragma unroll
             for (int ii = 0; ii < SB; ++ii)
 #pragma unroll
                 for (int jj = 0; jj < SB; ++jj) {
-                    acc[ii][jj] = irm_mfma16(qa[ii][j].x, ka[jj][j].x, acc[ii][jj]);
-                    acc[ii][jj] = irm_mfma16(qa[ii][j].y, ka[jj][j].y, acc[ii][jj]);
-                    acc[ii][jj] = irm_mfma16(qa[ii][j].z, ka[jj][j].z, acc[ii][jj]);
-                    acc[ii][jj] = irm_mfma16(qa[ii][j].w, ka[jj][j].w, acc[ii][jj]);
+                    acc[ii][jj] = irm_mfma16(qa[set][ii][j].x, ka[set][jj][j].x, acc[ii][jj]);
+                    acc[ii][jj] = irm_mfma16(qa[set][ii][j].y, ka[set][jj][j].y, acc[ii][jj]);
+                    acc[ii][jj] = irm_mfma16(qa[set][ii][j].z, ka[set][jj][j].z, acc[ii][jj]);
+                    acc[ii][jj] = irm_mfma16(qa[set][ii][j].w, ka[set][jj][j].w, acc[ii][jj]);
                 }
         }
+    };
+    fetch(0, nbeg);
+    for (int slab = nbeg; slab < nend; slab += 64) {
+        fetch(1, slab + 32);           // positions >= nend read as zero
+        consume(0);
+        fetch(0, slab + 64);
+        consume(1);
     }
 
     // partial record of this (b, head, chunk): G[c][c], nq[c], nk[c]
