@@ -36,6 +36,7 @@ struct GemmArgs {
     int ln_mode, act;
     float* stats_out;             // optional [B][2][N]: LayerNorm statistics of Y over its M channels
     float eps;                    // (single-pass launches only: every output channel lives in one workgroup)
+    int dbg;                      // timing experiments only (IRM_GEMM_DBG): 1 = no DMA, 2 = no stores
 };
 
 
@@ -264,6 +265,10 @@ __global__ __launch_bounds__(256) void gemm_pw_kernel(GemmArgs a) {
 
 __device__ __attribute__((noinline)) float irm_act_slow(float v, int act) { return irm_act(v, act); }
 
+// Masked-off lanes of the epilogue stores write here instead of being skipped, so that every wave
+// issues exactly PT*CT store instructions per pass and the counted vmcnt waits stay exact.
+__device__ float4 irm_dump[256 * 64];
+
 template <int N>
 __device__ __forceinline__ void irm_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -277,7 +282,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
     constexpr int STG = XS + CT * 256;          // floats per stage
     constexpr int WL = (CT + 3) / 4;            // weight DMA instructions per wave per stage
     constexpr int LPS = PT + WL;                // DMA instructions per wave per stage
-    static_assert((NS - 2) * LPS <= 63, "vmcnt field");
+    constexpr int NST = PT * CT;                // store instructions per wave per pass (always issued)
+    static_assert((NS - 2) * LPS + NST <= 63, "vmcnt field");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -319,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
     const int xcol = min(n0 + (lane * 4) % BN, a.N - 4);
 
     auto issue = [&](int it) {
+        if (a.dbg & 1) return;
         const int ci = it / S, s = it - ci * S;
         const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
         float* xb = smem + (it % NS) * STG;
@@ -357,13 +364,20 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
     for (int j = 0; j < NS - 1; ++j)
         if (j < TOT) issue(j);
 
-    int s = 0, ci = 0;
+    int s = 0, ci = 0, since_epi = 1 << 20;
     for (int it = 0; it < TOT; ++it) {
         // stage `it` has landed once at most `rem` younger stages are still in flight
+        // vmcnt retires in issue order and counts stores too: the NST stores of the last epilogue are
+        // younger than every DMA issued before it, so for the next NS-1 stages they are added to the
+        // number of operations allowed to stay in flight (otherwise each pass boundary would drain
+        // two prefetched stages and wait for write acknowledgements)
         const int rem = min(NS - 2, TOT - 1 - it);
-        if (rem >= 2 && NS >= 4) irm_wait_vmcnt<(NS >= 4 ? 2 : 0) * LPS>();
-        else if (rem == 1 && NS >= 3) irm_wait_vmcnt<LPS>();
-        else irm_wait_vmcnt<0>();
+        const bool st = since_epi <= NS - 1 && S >= NS - 1;
+        if (S < NS - 1 && since_epi <= NS - 1) irm_wait_vmcnt<0>();
+        else if (rem >= 2 && NS >= 4) { if (st) irm_wait_vmcnt<(NS >= 4 ? 2 : 0) * LPS + NST>(); else irm_wait_vmcnt<(NS >= 4 ? 2 : 0) * LPS>(); }
+        else if (rem == 1 && NS >= 3) { if (st) irm_wait_vmcnt<LPS + NST>(); else irm_wait_vmcnt<LPS>(); }
+        else { if (st) irm_wait_vmcnt<NST>(); else irm_wait_vmcnt<0>(); }
+        ++since_epi;
         asm volatile("s_barrier" ::: "memory");
         if (it + NS - 1 < TOT) issue(it + NS - 1);
         if (s == 0) {
@@ -441,14 +455,17 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
                 const bool row_ok = mt0 + c < a.mtiles && co < a.M;
 #pragma unroll
                 for (int p = 0; p < PT; ++p) {
-                    if (row_ok && pixs[p] < a.N)
-                        *reinterpret_cast<float4*>(Y + (long)co * a.N + pixs[p]) =
-                            make_float4(acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]);
+                    // masked lanes write a dump slot so that exactly NST store instructions are issued
+                    float4* dst = (row_ok && pixs[p] < a.N && !(a.dbg & 2))
+                        ? reinterpret_cast<float4*>(Y + (long)co * a.N + pixs[p])
+                        : irm_dump + ((blockIdx.x & 255) * 64 + lane);
+                    *dst = make_float4(acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]);
                     acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
             s = 0;
             ++ci;
+            since_epi = 1;
         }
     }
 }
@@ -520,6 +537,7 @@ extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long 
     a.bias = bias; a.stats = stats; a.lnw = lnw; a.lnb = lnb;
     a.M = M; a.K = K; a.N = N; a.mtiles = (M + 15) / 16; a.ksteps = 4 * ((K + 15) / 16);
     a.ln_mode = ln_mode; a.act = act; a.stats_out = stats_out; a.eps = eps;
+    a.dbg = getenv("IRM_GEMM_DBG") ? atoi(getenv("IRM_GEMM_DBG")) : 0;
     // fused output statistics need every output channel in one workgroup pass
     if (stats_out && (ct <= 0 || a.mtiles > ct)) return IRM_EINVAL;
     const int nchunks = (a.mtiles + (ct > 0 ? ct : 1) - 1) / (ct > 0 ? ct : 1);
