@@ -164,7 +164,7 @@ def main():
             tot_ms = sum(k["ms"] for k in ks.values())
             g = ks["gemm1x1"]
             tfl = g["flops"] / (g["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "gemm_pw_kernel (irm_gemm1x1_f32)", "bound": "mfma", "achieved": tfl,
+            out["roofline"] = {"kernel": "gemm_ring_kernel (irm_gemm1x1_f32)", "bound": "mfma", "achieved": tfl,
                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_F32_MFMA_TFLOPS,
                                "traffic": None, "launches": g["launches"],
                                "avg_launch_us": g["ms"] * 1e3 / g["launches"],
