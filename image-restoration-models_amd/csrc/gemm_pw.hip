@@ -27,6 +27,7 @@ struct GemmArgs {
     const float* X;  long x_bs;   // [B][K][N]
     float* Y;        long y_bs;   // [B][M][N]
     const float* R;  long r_bs;   // residual [B][M][N] or null
+    const float* rscale;          // optional [M]: y = acc + res * rscale[co] (MaIR skip_scale)
     const float* bias;            // [M] or null
     const float* stats;           // [B][2][N] mean, rstd (LN prologue) or null
     const float* lnw;             // [K]
@@ -242,7 +243,8 @@ __global__ __launch_bounds__(256) void gemm_pw_kernel(GemmArgs a) {
                 }
                 if (R && row_ok && pixs[p] < a.N) {
                     const float4 q = irm_ld4<VEC>(R + (long)co * a.N, pixs[p], a.N);
-                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                    const float sc = a.rscale ? a.rscale[co] : 1.0f;
+                    v.x = fmaf(q.x, sc, v.x); v.y = fmaf(q.y, sc, v.y); v.z = fmaf(q.z, sc, v.z); v.w = fmaf(q.w, sc, v.w);
                 }
                 acc[p][c] = (f32x4){v.x, v.y, v.z, v.w};
             }
@@ -444,8 +446,9 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
                 for (int c = 0; c < (RES ? CT : 0); ++c)
 #pragma unroll
                     for (int p = 0; p < PT; ++p) {
-                        acc[p][c][0] += rv[p][c].x; acc[p][c][1] += rv[p][c].y;
-                        acc[p][c][2] += rv[p][c].z; acc[p][c][3] += rv[p][c].w;
+                        const float sc = a.rscale ? a.rscale[min((mt0 + c) * 16 + r, a.M - 1)] : 1.0f;
+                        acc[p][c][0] = fmaf(rv[p][c].x, sc, acc[p][c][0]); acc[p][c][1] = fmaf(rv[p][c].y, sc, acc[p][c][1]);
+                        acc[p][c][2] = fmaf(rv[p][c].z, sc, acc[p][c][2]); acc[p][c][3] = fmaf(rv[p][c].w, sc, acc[p][c][3]);
                     }
             }
             if (a.stats_out) irm_stats_from_acc<PT, CT>(acc, mt0, a.M, a.N, r, pixs, a.stats_out + (long)b * 2 * a.N, a.eps);
@@ -524,7 +527,8 @@ static bool irm_force_generic() {
 extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long x_bs, float* y, long y_bs,
                                const float* res, long r_bs, const float* bias, const float* stats,
                                const float* lnw, const float* lnb, int ln_mode, int act, int B, int M, int K,
-                               int N, int ct, int ygroups, float* stats_out, float eps, hipStream_t stream) {
+                               int N, int ct, int ygroups, float* stats_out, float eps, const float* res_scale,
+                               hipStream_t stream) {
     if (!wp || !x || !y || B <= 0 || M <= 0 || K <= 0 || N <= 0) return IRM_EINVAL;
     if (ln_mode != IRM_LN_NONE && (!stats || !lnw || (ln_mode == IRM_LN_WITHBIAS && !lnb))) return IRM_EINVAL;
     if (ln_mode < 0 || ln_mode > 2 || act < 0 || act > 3) return IRM_EINVAL;
@@ -534,7 +538,7 @@ extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long 
                      irm_aligned16(y) && irm_aligned16(res) && irm_aligned16(stats);
     GemmArgs a;
     a.Wp = wp; a.w_bs = w_bs; a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.R = res; a.r_bs = r_bs;
-    a.bias = bias; a.stats = stats; a.lnw = lnw; a.lnb = lnb;
+    a.bias = bias; a.stats = stats; a.lnw = lnw; a.lnb = lnb; a.rscale = res ? res_scale : nullptr;
     a.M = M; a.K = K; a.N = N; a.mtiles = (M + 15) / 16; a.ksteps = 4 * ((K + 15) / 16);
     a.ln_mode = ln_mode; a.act = act; a.stats_out = stats_out; a.eps = eps;
     a.dbg = getenv("IRM_GEMM_DBG") ? atoi(getenv("IRM_GEMM_DBG")) : 0;

@@ -1,0 +1,314 @@
+// MaIR / LoSh2D kernels (src/mair/realDenoising/basicsr/models/archs/mairunet_arch.py:226-282):
+// the selective-scan SSM recurrence that the reference gets from the third-party mamba_ssm CUDA wheel
+// (`selective_scan_fn`, call site mairunet_arch.py:252-258), with the four nested-S scan orders
+// (shift_scanf_util.py:206-244), the dt projection (:243), the ShuffleAttn gate (:21-60, :273), the
+// direction sum (:274-275), out_norm and the SiLU(z) gate (:277-278) fused around it.
+//
+// Layout: the scan works channel-LAST (tokens [L][D]) so that at one time step the 64 lanes of a wave
+// (= 64 channels d) read one contiguous 256-byte piece; the per-step projections dt_raw / B / C of a
+// (direction, pixel) are one contiguous row [4*(R+2N)] read through the scalar cache.  The gather by the
+// scan order and the inverse scatter are index arithmetic inside the kernel (u is read at pixel
+// ids[k][t], y is written back to pixel ids[k][t]) - the 4x expanded tensors of the reference never exist.
+//
+// Parallelism over L: chunked scan.  Phase A scans every chunk from h = 0 and records its end state and
+// the chunk's total dt; phase B (tiny) carries the state across chunks, h_in[c+1] = exp(A*sum_dt[c]) h_in[c]
+// + h_end[c]; phase C rescans every chunk from its true initial state and emits y.  A work unit is one
+// wave: (batch, direction, 64-channel block, chunk); it keeps h[N], A[N] and the dt weights in registers.
+#include "irm_common.h"
+
+// ---------------------------------------------------------------------------
+// [B][R][C] -> [B][C][R] through a padded 32x32 LDS tile
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, long in_bs,
+                                                        float* __restrict__ out, long out_bs, int R, int C) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    const float* src = in + (long)b * in_bs;
+    float* dst = out + (long)b * out_bs;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, c = c0 + tx;
+        if (r < R && c < C) tile[ty + 8 * j][tx] = src[(long)r * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + 8 * j, r = r0 + tx;
+        if (r < R && c < C) dst[(long)c * R + r] = tile[tx][ty + 8 * j];
+    }
+}
+
+extern "C" int irm_transpose_f32(const float* in, long in_bs, float* out, long out_bs, int B, int R, int C,
+                                 hipStream_t stream) {
+    if (!in || !out || B <= 0 || R <= 0 || C <= 0 || B > 65535) return IRM_EINVAL;
+    dim3 grid((C + 31) / 32, (R + 31) / 32, B);
+    if (grid.y > 65535) return IRM_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, in_bs, out, out_bs, R, C);
+    return irm_launch_status();
+}
+
+// ---------------------------------------------------------------------------
+struct ScanArgs {
+    const float* xT;       // [B][L][D]    u, channel last
+    const float* pT;       // [B][L][4*J]  per pixel: for each direction k: dt_raw[R], B[N], C[N]   (J = R + 2N)
+    const int* ids;        // [4][L]       scan order: time t of direction k visits pixel ids[k][t]
+    const float* dtw;      // [4][D][R]
+    const float* dtb;      // [4][D]
+    const float* A;        // [4*D][N]     = -exp(A_logs)
+    const float* Dskip;    // [4*D]
+    float* yT;             // [B][4][L][D] (phase C)
+    float* state;          // [B][4][DB][nchunk][N][64]  chunk end states (A) -> chunk initial states (B)
+    float* sdt;            // [B][4][DB][nchunk][64]     sum of dt over the chunk
+    float* ysum;           // [B][4][DB][nchunk][64]     sum of y over the chunk (phase C)
+    int L, D, DB, chunk, nchunk;
+};
+
+__device__ __forceinline__ float irm_softplus(float x) { return x <= 20.0f ? log1pf(expf(x)) : x; }
+
+template <int N, int R, bool EMIT>
+__global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs a) {
+    constexpr int J = R + 2 * N;
+    constexpr int TU = 4;                                     // time steps fetched together
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x, kdb = blockIdx.y, b = blockIdx.z;
+    const int k = kdb / a.DB, db = kdb % a.DB;
+    const int d = db * 64 + lane;
+    const bool on = d < a.D;
+    const int dc = on ? d : a.D - 1;                          // idle lanes shadow a valid channel
+
+    float Ac[N], wdt[R], h[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) Ac[n] = a.A[((long)k * a.D + dc) * N + n];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wdt[r] = a.dtw[((long)k * a.D + dc) * R + r];
+    const float bias = a.dtb[k * a.D + dc];
+    const float dsk = a.Dskip[k * a.D + dc];
+
+    const long unit = (((long)b * 4 + k) * a.DB + db) * a.nchunk + c;
+    float* st = a.state + unit * N * 64;
+#pragma unroll
+    for (int n = 0; n < N; ++n) h[n] = EMIT ? st[n * 64 + lane] : 0.0f;
+
+    const int* ids = a.ids + (long)k * a.L;
+    const float* xT = a.xT + (long)b * a.L * a.D;
+    const float* pT = a.pT + (long)b * a.L * 4 * J + k * J;
+    float* yT = EMIT ? a.yT + ((long)b * 4 + k) * a.L * a.D : nullptr;
+    float sum_dt = 0.0f, sum_y = 0.0f;
+
+    const int t0 = c * a.chunk, t1 = min(t0 + a.chunk, a.L);
+    for (int t = t0; t < t1; t += TU) {
+        int p[TU];
+        float u[TU];
+#pragma unroll
+        for (int i = 0; i < TU; ++i) {
+            p[i] = __builtin_amdgcn_readfirstlane(ids[min(t + i, t1 - 1)]);
+            u[i] = xT[(long)p[i] * a.D + dc];
+        }
+#pragma unroll
+        for (int i = 0; i < TU; ++i) {
+            if (t + i < t1) {
+                const float* row = pT + (long)p[i] * 4 * J;          // wave-uniform row: dt_raw | B | C
+                float dt = bias;
+#pragma unroll
+                for (int r = 0; r < R; ++r) dt = fmaf(wdt[r], row[r], dt);
+                dt = irm_softplus(dt);
+                const float du = dt * u[i];
+                float y = dsk * u[i];
+#pragma unroll
+                for (int n = 0; n < N; ++n) {
+                    h[n] = fmaf(expf(dt * Ac[n]), h[n], du * row[R + n]);
+                    y = fmaf(h[n], row[R + N + n], y);
+                }
+                sum_dt += dt;
+                if (EMIT) {
+                    if (on) yT[(long)p[i] * a.D + d] = y;
+                    sum_y += y;
+                }
+            }
+        }
+    }
+    if (EMIT) {
+        a.ysum[unit * 64 + lane] = on ? sum_y : 0.0f;
+    } else {
+#pragma unroll
+        for (int n = 0; n < N; ++n) st[n * 64 + lane] = h[n];
+        a.sdt[unit * 64 + lane] = sum_dt;
+    }
+}
+
+// phase B: carry the state across the chunks of one (batch, direction, channel block); in place:
+// state[c] (end state of chunk c scanned from 0) becomes the true initial state of chunk c.
+template <int N>
+__global__ __launch_bounds__(64) void scan_carry_kernel(ScanArgs a) {
+    const int lane = threadIdx.x;
+    const int kdb = blockIdx.x, b = blockIdx.y;
+    const int k = kdb / a.DB, db = kdb % a.DB;
+    const int dc = min(db * 64 + lane, a.D - 1);
+    float Ac[N], h[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) { Ac[n] = a.A[((long)k * a.D + dc) * N + n]; h[n] = 0.0f; }
+    const long base = (((long)b * 4 + k) * a.DB + db) * a.nchunk;
+    for (int c = 0; c < a.nchunk; ++c) {
+        float* st = a.state + (base + c) * N * 64;
+        const float s = a.sdt[(base + c) * 64 + lane];
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const float e = st[n * 64 + lane];
+            st[n * 64 + lane] = h[n];
+            h[n] = fmaf(expf(Ac[n] * s), h[n], e);
+        }
+    }
+}
+
+template <int N, int R>
+static int scan_launch(const ScanArgs& a, int B, hipStream_t stream) {
+    dim3 g1(a.nchunk, 4 * a.DB, B), g2(4 * a.DB, B);
+    hipLaunchKernelGGL((scan_chunk_kernel<N, R, false>), g1, dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((scan_carry_kernel<N>), g2, dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((scan_chunk_kernel<N, R, true>), g1, dim3(64), 0, stream, a);
+    return irm_launch_status();
+}
+
+extern "C" int irm_selective_scan_f32(const float* xT, const float* pT, const int* ids, const float* dtw,
+                                      const float* dtb, const float* A, const float* Dskip, float* yT,
+                                      float* state, float* sdt, float* ysum, int B, int L, int D, int N, int R,
+                                      int chunk, hipStream_t stream) {
+    if (!xT || !pT || !ids || !dtw || !dtb || !A || !Dskip || !yT || !state || !sdt || !ysum) return IRM_EINVAL;
+    if (B <= 0 || L <= 0 || D <= 0 || chunk <= 0 || B > 65535) return IRM_EINVAL;
+    ScanArgs a{xT, pT, ids, dtw, dtb, A, Dskip, yT, state, sdt, ysum, L, D, (D + 63) / 64, chunk,
+               (L + chunk - 1) / chunk};
+    if (4 * a.DB > 65535) return IRM_EINVAL;
+    if (N == 4 && R == 3) return scan_launch<4, 3>(a, B, stream);
+    if (N == 8 && R == 6) return scan_launch<8, 6>(a, B, stream);
+    if (N == 16 && R == 12) return scan_launch<16, 12>(a, B, stream);
+    if (N == 32 && R == 24) return scan_launch<32, 24>(a, B, stream);
+    return IRM_EINVAL;                                  // (d_state, dt_rank) pairs of MaIRUNet / MaIR
+}
+
+// ---------------------------------------------------------------------------
+// ShuffleAttn gate: g[b][k'][d] = sigmoid(bias[4d+k'] + sum_k W[4d+k'][k] * mean_HW(y[k][d]))
+__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ ysum, const float* __restrict__ gw,
+                                                   const float* __restrict__ gb, float* __restrict__ gate, int D,
+                                                   int DB, int nchunk, float inv_L) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;           // e = kq * D + d
+    if (e >= 4 * D) return;
+    const int kq = e / D, d = e % D;
+    const int db = d >> 6, lane = d & 63;
+    float acc = gb[4 * d + kq];
+    for (int k = 0; k < 4; ++k) {
+        const float* p = ysum + ((((long)b * 4 + k) * DB + db) * nchunk) * 64 + lane;
+        float s = 0.0f;
+        for (int c = 0; c < nchunk; ++c) s += p[(long)c * 64];           // fixed order
+        acc = fmaf(gw[(4 * d + kq) * 4 + k], s * inv_L, acc);
+    }
+    gate[(long)b * 4 * D + e] = 1.0f / (1.0f + expf(-acc));
+}
+
+// combine: v[p][d] = sum_k y[k][p][d] * g[k][d]; LayerNorm over d (out_norm); * silu(z[d][p]); planar output.
+// One workgroup = 32 pixels; a wave normalises 8 pixels (lanes over d), the tile is transposed through LDS.
+struct CombArgs {
+    const float* yT;      // [B][4][L][D]
+    const float* gate;    // [B][4][D]
+    const float* nw;      // [D] out_norm weight
+    const float* nb;      // [D] out_norm bias
+    const float* z;       // planar [B][D][L] (batch stride z_bs)
+    long z_bs;
+    float* out;           // planar [B][D][L]
+    long out_bs;
+    int L, D;
+    float eps;
+};
+
+template <int DV>      // DV = ceil(D / 64) values per lane
+__global__ __launch_bounds__(256) void combine_kernel(CombArgs a) {
+    extern __shared__ float tile[];                          // [D][33]
+    const int b = blockIdx.y, p0 = blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* g = a.gate + (long)b * 4 * a.D;
+    float gk[4][DV], nw[DV], nb[DV];
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+        const int d = min(i * 64 + lane, a.D - 1);
+        nw[i] = a.nw[d]; nb[i] = a.nb[d];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gk[k][i] = g[k * a.D + d];
+    }
+    for (int q = 0; q < 8; ++q) {
+        const int px = wave * 8 + q, p = p0 + px;
+        if (p >= a.L) break;
+        float v[DV], s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DV; ++i) {
+            const int d = i * 64 + lane;
+            float t = 0.0f;
+            if (d < a.D) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    t = fmaf(a.yT[(((long)b * 4 + k) * a.L + p) * a.D + d], gk[k][i], t);
+            }
+            v[i] = t;
+            s += t;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)a.D;
+        float sq = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DV; ++i) {
+            const float dlt = (i * 64 + lane < a.D) ? v[i] - mean : 0.0f;
+            sq += dlt * dlt;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        const float rstd = 1.0f / sqrtf(sq / (float)a.D + a.eps);
+#pragma unroll
+        for (int i = 0; i < DV; ++i) {
+            const int d = i * 64 + lane;
+            if (d < a.D) tile[d * 33 + px] = (v[i] - mean) * rstd * nw[i] + nb[i];
+        }
+    }
+    __syncthreads();
+    const float* z = a.z + (long)b * a.z_bs;
+    float* out = a.out + (long)b * a.out_bs;
+    const int px = threadIdx.x & 31;
+    if (p0 + px < a.L) {
+        for (int d = threadIdx.x >> 5; d < a.D; d += 8) {
+            const float zz = z[(long)d * a.L + p0 + px];
+            out[(long)d * a.L + p0 + px] = tile[d * 33 + px] * (zz / (1.0f + expf(-zz)));
+        }
+    }
+}
+
+extern "C" int irm_losh_combine_f32(const float* ysum, const float* gw, const float* gb, float* gate,
+                                    const float* yT, const float* nw, const float* nb, const float* z, long z_bs,
+                                    float* out, long out_bs, int B, int L, int D, int nchunk, float eps,
+                                    hipStream_t stream) {
+    if (!ysum || !gw || !gb || !gate || !yT || !nw || !nb || !z || !out) return IRM_EINVAL;
+    if (B <= 0 || L <= 0 || D <= 0 || nchunk <= 0 || B > 65535 || D > 1024) return IRM_EINVAL;
+    const int DB = (D + 63) / 64;
+    hipLaunchKernelGGL(gate_kernel, dim3((4 * D + 255) / 256, B), dim3(256), 0, stream, ysum, gw, gb, gate, D, DB,
+                       nchunk, 1.0f / (float)L);
+    CombArgs a{yT, gate, nw, nb, z, z_bs, out, out_bs, L, D, eps};
+    const size_t lds = (size_t)D * 33 * sizeof(float);
+    dim3 grid((L + 31) / 32, B);
+#define IRM_COMB(DVV)                                                                                              \
+    do {                                                                                                           \
+        static bool cfg = false;                                                                                   \
+        if (!cfg) {                                                                                                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&combine_kernel<DVV>),                           \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)         \
+                return IRM_ELAUNCH;                                                                                \
+            cfg = true;                                                                                            \
+        }                                                                                                          \
+        hipLaunchKernelGGL(combine_kernel<DVV>, grid, dim3(256), lds, stream, a);                                  \
+    } while (0)
+    if (DB <= 2) IRM_COMB(2);
+    else if (DB <= 3) IRM_COMB(3);
+    else if (DB <= 6) IRM_COMB(6);
+    else if (DB <= 12) IRM_COMB(12);
+    else IRM_COMB(16);
+#undef IRM_COMB
+    return irm_launch_status();
+}

@@ -86,7 +86,7 @@ def ln_stats(x: torch.Tensor, stats: torch.Tensor, eps: float = 1e-5):
 
 def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, *, res=None, bias=None,
             stats=None, lnw=None, lnb=None, ln_mode=LN_NONE, act=ACT_NONE, w_bs: int = 0, ct: int | None = None,
-            ygroups: int | None = None, stats_out=None, eps: float = 1e-5):
+            ygroups: int | None = None, stats_out=None, eps: float = 1e-5, res_scale=None):
     """y = act(W @ LN(x) + bias) (+ res); wp from _hip.pack_gemm_weight.
     stats_out: optional [B,2,N] buffer receiving the LayerNorm statistics of y (needs M <= 16*ct)."""
     _chk(x, "x"), _chk(y, "y")
@@ -110,7 +110,7 @@ def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, 
     _launch("gemm1x1", 2.0 * B * M * K * N, nbytes, "irm_gemm1x1_f32", _hip.ptr(wp), int(w_bs), _hip.ptr(x), _bs(x),
             _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), _hip.ptr(stats), _hip.ptr(lnw),
             _hip.ptr(lnb), int(ln_mode), int(act), B, M, K, N, ct, ygroups, _hip.ptr(stats_out), float(eps),
-            tag=f"M{M} K{K} N{N} B{B} ln{int(ln_mode)} res{int(res is not None)} ct{ct} yg{ygroups}")
+            _hip.ptr(res_scale), tag=f"M{M} K{K} N{N} B{B} ln{int(ln_mode)} res{int(res is not None)} ct{ct} yg{ygroups}")
 
 
 def dwconv3x3(x, w9, y, *, bias=None, act=ACT_NONE):
@@ -182,3 +182,36 @@ def conv3x3(wp, x, y, ci: int, co: int, *, bias=None, relu1=False, res=None, res
     _launch("conv3x3", 18.0 * B * ci * co * H * W, nbytes, "irm_conv3x3_f32", _hip.ptr(wp), _hip.ptr(x), _bs(x),
             _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), B, ci, co, H, W, int(relu1), int(res_mode),
             int(relu2), int(store_mode), ct, ygroups, tag=f"ci{ci} co{co} {H}x{W} B{B} ct{ct} yg{ygroups} st{store_mode}")
+
+
+# --------------------------------------------------------------------------- MaIR / LoSh2D
+def transpose(src: torch.Tensor, dst: torch.Tensor, R: int, C: int):
+    """src [B][R][C] (batch stride free) -> dst [B][C][R]."""
+    B = src.shape[0]
+    _launch("transpose", 0.0, 8.0 * B * R * C, "irm_transpose_f32", _hip.ptr(src), src.stride(0), _hip.ptr(dst),
+            dst.stride(0), B, R, C, tag=f"R{R} C{C} B{B}")
+
+
+def scan_plan(B: int, L: int, D: int):
+    """(chunk, nchunk, DB): time steps per wave so that roughly 2 waves per SIMD exist."""
+    DB = (D + 63) // 64
+    nchunk = max(1, min(-(-L // 32), -(-2048 // (B * 4 * DB))))
+    chunk = max(32, -(-(-(-L // nchunk)) // 4) * 4)
+    return chunk, -(-L // chunk), DB
+
+
+def selective_scan(xT, pT, ids, dtw, dtb, A, Dskip, yT, state, sdt, ysum, B, L, D, N, R, chunk):
+    """irm_selective_scan_f32 (include/irm_hip.h): all four scan directions, gather/scatter fused."""
+    flops = B * 4.0 * L * D * (2 * R + 9 * N + 12)
+    nbytes = 4.0 * B * L * (D + 4 * (R + 2 * N) + 4 * D)
+    _launch("selective_scan", flops, nbytes, "irm_selective_scan_f32", _hip.ptr(xT), _hip.ptr(pT), _hip.ptr(ids),
+            _hip.ptr(dtw), _hip.ptr(dtb), _hip.ptr(A), _hip.ptr(Dskip), _hip.ptr(yT), _hip.ptr(state), _hip.ptr(sdt),
+            _hip.ptr(ysum), B, L, D, N, R, chunk, tag=f"L{L} D{D} N{N} B{B} chunk{chunk}")
+
+
+def losh_combine(ysum, gw, gb, gate, yT, nw, nb, z, out, B, L, D, nchunk, eps=1e-5):
+    """gate + direction sum + out_norm + silu(z) gate -> planar out [B, D, H, W]."""
+    _chk(z, "z"), _chk(out, "out")
+    _launch("losh_combine", 12.0 * B * L * D, 4.0 * B * L * D * 6, "irm_losh_combine_f32", _hip.ptr(ysum), _hip.ptr(gw),
+            _hip.ptr(gb), _hip.ptr(gate), _hip.ptr(yT), _hip.ptr(nw), _hip.ptr(nb), _hip.ptr(z), _bs(z), _hip.ptr(out),
+            _bs(out), B, L, D, nchunk, float(eps), tag=f"L{L} D{D} B{B}")

@@ -18,16 +18,17 @@ import numpy as np
 import torch
 from torch.nn import Module
 
-from . import _hip, dncnn, rednet, restormer
+from . import _hip, dncnn, mair, rednet, restormer
 from .configs import PATCH_CONFIG, ROOT_RESULTS_DIR, ROOT_WEIGHTS_DIR
 from .dncnn import DnCNN
 from .rednet import REDNet
 from .restormer import Restormer
+from .mair import MaIRUNet
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
 #: model classes whose forward is the HIP path (isinstance dispatch as in utils.py:280/292)
-_PAD8_MODELS = (Restormer,)
+_PAD8_MODELS = (Restormer, MaIRUNet)
 
 
 def get_model_total_parameters(model: Module) -> int:
@@ -121,8 +122,18 @@ def get_model_instance(task, subtask, model_name, device: torch.device, gray=Fal
                 return restormer.get_model(_restormer_opt('DefocusDeblur_Single_8bit_Restormer'), device)
             if subtask == 'motion':
                 return restormer.get_model(_restormer_opt('Deblurring_Restormer'), device)
-    elif model_key in ('DeblurGANv2', 'MaIR'):
-        raise NotImplementedError(f'{model_key} is not built yet in the MI355X path (see DESIGN.md scope table)')
+    elif model_key == 'MaIR':
+        opt_dir = os.path.join(_PKG_DIR, 'mair', 'options')
+        if task == 'denoising':
+            if subtask == 'gaussian' and not gray and sigma is not None:
+                raise NotImplementedError('MaIR (flat, mair_arch.py) for colour Gaussian denoising is not built yet '
+                                          'in the MI355X path; MaIRUNet (real denoising / motion deblurring) is')
+            if subtask == 'real':
+                return mair.get_model(os.path.join(opt_dir, 'test_MaIR_RealDN.yml'))
+        if task == 'deblurring' and subtask == 'motion':
+            return mair.get_model(os.path.join(opt_dir, 'test_MaIR_MotionDeblur.yml'))
+    elif model_key == 'DeblurGANv2':
+        raise NotImplementedError('DeblurGANv2 is not built yet in the MI355X path (see DESIGN.md scope table)')
     raise ValueError('No model instance found for current configuration.')
 
 

@@ -67,12 +67,14 @@ int irm_ln_stats_f32(const float* x, long x_bs, float* stats, int B, int C, int 
  * passes (>=1).  stats_out (optional, NULL to skip): [B][2][N] LayerNorm
  * statistics (mean, 1/sqrt(var+eps)) of y over its M channels for the NEXT
  * LayerNorm, produced in the epilogue; needs ceil(M/16) <= ct (one pass).
+ * res_scale (optional, [M]): y = ... + res * res_scale[co] (MaIR's skip_scale,
+ * mairunet_arch.py:375-377).
  * Operands whose rows are 16-byte aligned (N % 4 == 0, aligned bases/strides)
  * take the LDS-DMA ring kernel, anything else an exact scalar-path kernel. */
 int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long x_bs, float* y, long y_bs,
                     const float* res, long r_bs, const float* bias, const float* stats, const float* lnw,
                     const float* lnb, int ln_mode, int act, int B, int M, int K, int N, int ct, int ygroups,
-                    float* stats_out, float eps, irm_stream_t stream);
+                    float* stats_out, float eps, const float* res_scale, irm_stream_t stream);
 
 /* Depth-wise 3x3 convolution, zero pad 1: y[b][c] = act(dw3x3(x[b][c]; w[c]) + bias[c]).
  * Replaces Attention.qkv_dwconv (restormer.py:106) and MaIR's conv2d+SiLU.
@@ -138,6 +140,32 @@ int irm_tile_extract(const void* img, int is_u16, const int* origins, const doub
 int irm_window_blend(const float* pred, const int* origins, const float* window, void* out, int is_u16,
                      const void* target, unsigned long long* sse, int H, int W, int Co, int Cp, int th, int tw,
                      int ph, int pw, int ps, int T, float post_scale, float post_shift, irm_stream_t stream);
+
+/* [B][R][C] -> [B][C][R] (planar NCHW <-> channel-last tokens around the selective scan). */
+int irm_transpose_f32(const float* in, long in_bs, float* out, long out_bs, int B, int R, int C,
+                      irm_stream_t stream);
+
+/* Selective-scan SSM of MaIR's LoSh2D.forward_core (mairunet_arch.py:226-261), replacing the third-party
+ * mamba_ssm `selective_scan_fn(u, delta, A, B, C, D, delta_bias, delta_softplus=True)` (call site :252-258)
+ * together with the scan-order gather / inverse gather (shift_scanf_util.py:206-244) and dt_proj (:243):
+ *   for direction k, time t, pixel p = ids[k][t], channel d:
+ *     dt = softplus(dtb[k][d] + sum_r dtw[k][d][r] * pT[p][k*J + r])                      J = R + 2N
+ *     h[n] = exp(dt * A[k*D+d][n]) * h[n] + dt * pT[p][k*J + R + n] * xT[p][d]
+ *     yT[k][p][d] = sum_n h[n] * pT[p][k*J + R + N + n] + Dskip[k*D+d] * xT[p][d]
+ * xT [B][L][D], pT [B][L][4J] channel-last; ids [4][L] int32 (device); A = -exp(A_logs).
+ * Chunked over L (chunk steps per wave): workspaces state [B][4][DB][nchunk][N][64], sdt and ysum
+ * [B][4][DB][nchunk][64] with DB = ceil(D/64), nchunk = ceil(L/chunk); ysum receives per-chunk sums of y
+ * (for the ShuffleAttn mean).  (N, R) in {(4,3), (8,6), (16,12), (32,24)}. */
+int irm_selective_scan_f32(const float* xT, const float* pT, const int* ids, const float* dtw, const float* dtb,
+                           const float* A, const float* Dskip, float* yT, float* state, float* sdt, float* ysum,
+                           int B, int L, int D, int N, int R, int chunk, irm_stream_t stream);
+
+/* After the scan: ShuffleAttn gate g = sigmoid(W * mean_HW(y) + b) per (direction, channel)
+ * (mairunet_arch.py:21-60, :273; gw [4D][4], gb [4D]), direction sum (:274-275), out_norm LayerNorm over D
+ * (:277) and * silu(z) (:278); z and out planar [B][D][L].  gate: workspace [B][4][D]. */
+int irm_losh_combine_f32(const float* ysum, const float* gw, const float* gb, float* gate, const float* yT,
+                         const float* nw, const float* nb, const float* z, long z_bs, float* out, long out_bs,
+                         int B, int L, int D, int nchunk, float eps, irm_stream_t stream);
 
 #ifdef __cplusplus
 }

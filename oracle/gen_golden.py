@@ -14,7 +14,7 @@ What it does
      the max-abs differences in tests/golden/MANIFEST.json;
   3. stores the REFERENCE outputs (not the oracle's) as golden vectors.
 
-Usage: python oracle/gen_golden.py [--only restormer|tiler|convnets|ops]
+Usage: python oracle/gen_golden.py [--only restormer|tiler|convnets|ops|mair]
 """
 from __future__ import annotations
 
@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 import irm_amd  # noqa: E402
 from irm_amd import synth  # noqa: E402
-from oracle import convnets_ref, restormer_ref, tiler_ref  # noqa: E402
+from oracle import convnets_ref, mair_ref, restormer_ref, tiler_ref  # noqa: E402
 
 torch.manual_seed(0)
 torch.set_grad_enabled(False)
@@ -287,6 +287,104 @@ def gen_tiler(ref, manifest):
     np.savez_compressed(os.path.join(GOLD, "tiler.npz"), **out)
 
 
+MAIR_NET_G = dict(inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8], num_refinement_blocks=4,
+                  ssm_ratio=2.0, flp_ratio=4.0, mlp_ratio=1.5, bias=False, dual_pixel_task=False, img_size=32,
+                  scan_len=4, batch_size=1, dynamic_ids=False)      # test_MaIR_RealDN.yml network_g (img_size shrunk)
+
+
+def import_reference_mairunet():
+    """Import the reference's mairunet_arch.py itself.  Absent third-party modules are stubbed: timm.layers
+    (DropPath -> identity, to_2tuple, trunc_normal_), the BasicSR registry, and mamba_ssm's CUDA
+    selective_scan_fn, for which oracle/mair_ref.selective_scan stands in (that op stays unpinned)."""
+    import importlib
+    import torch.nn as nn
+    base = "/root/reference/src/mair"
+    for k in [k for k in sys.modules if k == "mair" or k.startswith("mair.")]:
+        del sys.modules[k]          # drop the empty stubs import_reference() installed for src/utils.py
+
+    def pkg(name, path=None, **attrs):
+        m = types.ModuleType(name)
+        if path:
+            m.__path__ = [path]
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class DropPath(nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+
+    pkg("timm")
+    pkg("timm.layers", DropPath=DropPath, to_2tuple=lambda v: (v, v) if not isinstance(v, (tuple, list)) else tuple(v),
+        trunc_normal_=lambda *a, **k: None)
+    pkg("mamba_ssm")
+    pkg("mamba_ssm.ops")
+    pkg("mamba_ssm.ops.selective_scan_interface", selective_scan_fn=mair_ref.selective_scan,
+        selective_scan_ref=mair_ref.selective_scan)
+
+    class _Reg:
+        def register(self, *a, **k):
+            return lambda cls: cls
+    pkg("mair", base)
+    pkg("mair.basicsr", base + "/basicsr")
+    pkg("mair.basicsr.utils", base + "/basicsr/utils")
+    pkg("mair.basicsr.utils.registry", ARCH_REGISTRY=_Reg())
+    pkg("mair.realDenoising", base + "/realDenoising")
+    pkg("mair.realDenoising.basicsr", base + "/realDenoising/basicsr")
+    pkg("mair.realDenoising.basicsr.models", base + "/realDenoising/basicsr/models")
+    pkg("mair.realDenoising.basicsr.models.archs", base + "/realDenoising/basicsr/models/archs")
+    return importlib.import_module("mair.realDenoising.basicsr.models.archs.mairunet_arch")
+
+
+def gen_mair(ref, manifest):
+    from irm_amd.mair import SYNTH_RULES as MAIR_RULES
+    arch = import_reference_mairunet()
+    out = {}
+    # (6) scan-id tables straight from the reference's generator
+    ssu = sys.modules["mair.realDenoising.basicsr.models.archs.shift_scanf_util"]
+    for (h, w, sl) in [(4, 8, 4), (16, 16, 4), (6, 10, 4), (5, 7, 4), (32, 24, 4)]:
+        a, ai = ssu.mair_ids_generate((1, 1, h, w), scan_len=sl)
+        b, bi = mair_ref.scan_ids(h, w, sl)
+        assert torch.equal(a.reshape(4, -1), b) and torch.equal(ai.reshape(4, -1), bi)
+        out[f"ids_{h}x{w}_s{sl}"] = a.reshape(4, -1).numpy().astype(np.int32)
+    net = arch.MaIRUNet(**MAIR_NET_G)
+    shapes = shapes_of(net)
+    manifest["mairunet_param_shapes"] = {k: list(v) for k, v in shapes.items()}
+    sd = synth.synth_state_dict(shapes, seed=42, rules=MAIR_RULES)
+    net.load_state_dict(sd, strict=True)
+    net.train()      # eval-mode forward cannot run on CPU (ids only bound under cuda, mairunet_arch.py:667-671);
+    #                  train mode is the same arithmetic (no BN, no dropout, DropPath(0))
+    for (h, w) in [(32, 32), (24, 40)]:
+        x = synth_input(f"mair_in_{h}x{w}", (1, 3, h, w))
+        net.trainig_img_size = -1
+        y_ref = net(x)
+        y_orc = mair_ref.mairunet_forward(x, sd, scan_len=4)
+        d = maxabs(y_ref, y_orc)
+        manifest.setdefault("oracle_vs_reference", {})[f"mairunet/{h}x{w}(scan op = oracle stand-in)"] = d
+        print(f"mairunet {h}x{w}: oracle-vs-reference max-abs {d:.3e} |y-x| mean {float((y_ref - x).abs().mean()):.4f}"
+              f" range [{float(y_ref.min()):.3f},{float(y_ref.max()):.3f}]")
+        assert d <= 2e-5
+        out[f"mairunet_{h}x{w}"] = y_ref.numpy()
+    # one VSSBlock per level shape, reference sub-module outputs
+    for (c, n, ratio, h, w) in [(48, 4, 4.0, 16, 24), (96, 8, 1.5, 8, 16), (384, 32, 1.5, 8, 8)]:
+        blk = arch.VSSBlock(hidden_dim=c, drop_path=0.0, norm_layer=torch.nn.LayerNorm, attn_drop_rate=0,
+                            ssm_ratio=2.0, d_state=n, mlp_ratio=ratio)
+        bsd = synth.synth_state_dict(shapes_of(blk), seed=21, rules=MAIR_RULES)
+        blk.load_state_dict(bsd, strict=True)
+        ids, inv = ssu.mair_ids_generate((1, 1, h, w), scan_len=4)
+        x = synth_input(f"vss_in_{c}", (2, h * w, c), -1.0, 1.0)
+        y = blk(x, (ids, inv, None, None), (h, w))
+        d = maxabs(y, mair_ref.vss_block(x, bsd, "", (h, w), ids.reshape(4, -1), inv.reshape(4, -1)))
+        manifest["oracle_vs_reference"][f"mairunet/vssblock_c{c}"] = d
+        print(f"vssblock c{c}: oracle-vs-reference {d:.3e}")
+        assert d <= 2e-5
+        out[f"vss_c{c}_{h}x{w}"] = y.numpy()
+    np.savez_compressed(os.path.join(GOLD, "mair.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -295,7 +393,8 @@ def main():
     mpath = os.path.join(GOLD, "MANIFEST.json")
     manifest = json.load(open(mpath)) if os.path.exists(mpath) else {}
     ref = import_reference()
-    steps = {"ops": gen_ops, "restormer": gen_restormer, "convnets": gen_convnets, "tiler": gen_tiler}
+    steps = {"ops": gen_ops, "restormer": gen_restormer, "convnets": gen_convnets, "tiler": gen_tiler,
+             "mair": gen_mair}      # mair last: it re-stubs the `mair` package for the reference's arch file
     for k, fn in steps.items():
         if args.only in (None, k):
             fn(ref, manifest)
