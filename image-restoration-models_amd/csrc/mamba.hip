@@ -58,18 +58,20 @@ struct ScanArgs {
     const float* A;        // [4*D][N]     = -exp(A_logs)
     const float* Dskip;    // [4*D]
     float* yT;             // [B][4][L][D] (phase C)
-    float* state;          // [B][4][DB][nchunk][N][64]  chunk end states (A) -> chunk initial states (B)
+    float* state;          // [2][B][4][DB][nchunk][N][64]  [0]: chunk end states (phase A), [1]: chunk initial states (phase B)
+    long state_half;       // elements of one half
     float* sdt;            // [B][4][DB][nchunk][64]     sum of dt over the chunk
     float* ysum;           // [B][4][DB][nchunk][64]     sum of y over the chunk (phase C)
     int L, D, DB, chunk, nchunk;
 };
 
-__device__ __forceinline__ float irm_softplus(float x) { return x <= 20.0f ? log1pf(expf(x)) : x; }
+// softplus with the hardware exp2/log2 (abs. error ~1e-7 on dt, far inside the 1e-3 output budget)
+__device__ __forceinline__ float irm_softplus(float x) { return x <= 20.0f ? __logf(1.0f + __expf(x)) : x; }
 
 template <int N, int R, bool EMIT>
 __global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs a) {
     constexpr int J = R + 2 * N;
-    constexpr int TU = 4;                                     // time steps fetched together
+    constexpr int TU = 8;                                     // time steps fetched together
     const int lane = threadIdx.x;
     const int c = blockIdx.x, kdb = blockIdx.y, b = blockIdx.z;
     const int k = kdb / a.DB, db = kdb % a.DB;
@@ -79,14 +81,14 @@ __global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs a) {
 
     float Ac[N], wdt[R], h[N];
 #pragma unroll
-    for (int n = 0; n < N; ++n) Ac[n] = a.A[((long)k * a.D + dc) * N + n];
+    for (int n = 0; n < N; ++n) Ac[n] = a.A[((long)k * a.D + dc) * N + n] * 1.44269504088896341f;   // exp(x) = exp2(x log2 e)
 #pragma unroll
     for (int r = 0; r < R; ++r) wdt[r] = a.dtw[((long)k * a.D + dc) * R + r];
     const float bias = a.dtb[k * a.D + dc];
     const float dsk = a.Dskip[k * a.D + dc];
 
     const long unit = (((long)b * 4 + k) * a.DB + db) * a.nchunk + c;
-    float* st = a.state + unit * N * 64;
+    float* st = a.state + (EMIT ? a.state_half : 0) + unit * N * 64;
 #pragma unroll
     for (int n = 0; n < N; ++n) h[n] = EMIT ? st[n * 64 + lane] : 0.0f;
 
@@ -96,30 +98,37 @@ __global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs a) {
     float* yT = EMIT ? a.yT + ((long)b * 4 + k) * a.L * a.D : nullptr;
     float sum_dt = 0.0f, sum_y = 0.0f;
 
+    // The per-step row [dt_raw | B | C] is wave-uniform.  It is fetched with ONE coalesced vector load
+    // per step (lane j holds element j) for TU steps ahead, and its elements are broadcast with
+    // v_readlane when used - nothing in the dependent chain waits on memory.
+    constexpr int JV = (J + 63) / 64;
     const int t0 = c * a.chunk, t1 = min(t0 + a.chunk, a.L);
     for (int t = t0; t < t1; t += TU) {
         int p[TU];
-        float u[TU];
+        float u[TU], rowv[TU][JV];
 #pragma unroll
         for (int i = 0; i < TU; ++i) {
             p[i] = __builtin_amdgcn_readfirstlane(ids[min(t + i, t1 - 1)]);
             u[i] = xT[(long)p[i] * a.D + dc];
+#pragma unroll
+            for (int jv = 0; jv < JV; ++jv) rowv[i][jv] = pT[(long)p[i] * 4 * J + min(jv * 64 + lane, J - 1)];
         }
 #pragma unroll
         for (int i = 0; i < TU; ++i) {
             if (t + i < t1) {
-                const float* row = pT + (long)p[i] * 4 * J;          // wave-uniform row: dt_raw | B | C
+#define IRM_ROW(j) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowv[i][(j) / 64]), (j) % 64))
                 float dt = bias;
 #pragma unroll
-                for (int r = 0; r < R; ++r) dt = fmaf(wdt[r], row[r], dt);
+                for (int r = 0; r < R; ++r) dt = fmaf(wdt[r], IRM_ROW(r), dt);
                 dt = irm_softplus(dt);
                 const float du = dt * u[i];
                 float y = dsk * u[i];
 #pragma unroll
                 for (int n = 0; n < N; ++n) {
-                    h[n] = fmaf(expf(dt * Ac[n]), h[n], du * row[R + n]);
-                    y = fmaf(h[n], row[R + N + n], y);
+                    h[n] = fmaf(__builtin_amdgcn_exp2f(dt * Ac[n]), h[n], du * IRM_ROW(R + n));
+                    y = fmaf(h[n], IRM_ROW(R + N + n), y);
                 }
+#undef IRM_ROW
                 sum_dt += dt;
                 if (EMIT) {
                     if (on) yT[(long)p[i] * a.D + d] = y;
@@ -137,8 +146,9 @@ __global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs a) {
     }
 }
 
-// phase B: carry the state across the chunks of one (batch, direction, channel block); in place:
-// state[c] (end state of chunk c scanned from 0) becomes the true initial state of chunk c.
+// phase B: carry the state across the chunks of one (batch, direction, channel block):
+// h_in[0] = 0, h_in[c+1] = exp(A * sum_dt[c]) * h_in[c] + h_end[c].  Inputs and outputs are separate
+// buffers so the loads of the next chunks are in flight while the dependent chain advances.
 template <int N>
 __global__ __launch_bounds__(64) void scan_carry_kernel(ScanArgs a) {
     const int lane = threadIdx.x;
@@ -149,16 +159,34 @@ __global__ __launch_bounds__(64) void scan_carry_kernel(ScanArgs a) {
 #pragma unroll
     for (int n = 0; n < N; ++n) { Ac[n] = a.A[((long)k * a.D + dc) * N + n]; h[n] = 0.0f; }
     const long base = (((long)b * 4 + k) * a.DB + db) * a.nchunk;
+    const float* __restrict__ hend = a.state + base * N * 64 + lane;
+    float* __restrict__ hin = a.state + a.state_half + base * N * 64 + lane;
+    const float* __restrict__ sdt = a.sdt + base * 64 + lane;
+#pragma unroll 4
     for (int c = 0; c < a.nchunk; ++c) {
-        float* st = a.state + (base + c) * N * 64;
-        const float s = a.sdt[(base + c) * 64 + lane];
+        const float s = sdt[(long)c * 64];
+        float e[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) e[n] = hend[((long)c * N + n) * 64];
 #pragma unroll
         for (int n = 0; n < N; ++n) {
-            const float e = st[n * 64 + lane];
-            st[n * 64 + lane] = h[n];
-            h[n] = fmaf(expf(Ac[n] * s), h[n], e);
+            hin[((long)c * N + n) * 64] = h[n];
+            h[n] = fmaf(__expf(Ac[n] * s), h[n], e[n]);
         }
     }
+}
+
+// per (batch, direction, channel block): ysum[chunk 0] <- sum over chunks (fixed order: 4 interleaved
+// partial sums combined in wave order), so the gate reads one value per channel
+__global__ __launch_bounds__(256) void ysum_reduce_kernel(float* __restrict__ ysum, int nchunk) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* p = ysum + (long)blockIdx.x * nchunk * 64 + lane;
+    float s = 0.0f;
+    for (int c = w; c < nchunk; c += 4) s += p[(long)c * 64];
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0) p[0] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
 template <int N, int R>
@@ -176,8 +204,9 @@ extern "C" int irm_selective_scan_f32(const float* xT, const float* pT, const in
                                       int chunk, hipStream_t stream) {
     if (!xT || !pT || !ids || !dtw || !dtb || !A || !Dskip || !yT || !state || !sdt || !ysum) return IRM_EINVAL;
     if (B <= 0 || L <= 0 || D <= 0 || chunk <= 0 || B > 65535) return IRM_EINVAL;
-    ScanArgs a{xT, pT, ids, dtw, dtb, A, Dskip, yT, state, sdt, ysum, L, D, (D + 63) / 64, chunk,
+    ScanArgs a{xT, pT, ids, dtw, dtb, A, Dskip, yT, state, 0, sdt, ysum, L, D, (D + 63) / 64, chunk,
                (L + chunk - 1) / chunk};
+    a.state_half = (long)B * 4 * a.DB * a.nchunk * N * 64;
     if (4 * a.DB > 65535) return IRM_EINVAL;
     if (N == 4 && R == 3) return scan_launch<4, 3>(a, B, stream);
     if (N == 8 && R == 6) return scan_launch<8, 6>(a, B, stream);
@@ -198,9 +227,7 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ ysu
     const int db = d >> 6, lane = d & 63;
     float acc = gb[4 * d + kq];
     for (int k = 0; k < 4; ++k) {
-        const float* p = ysum + ((((long)b * 4 + k) * DB + db) * nchunk) * 64 + lane;
-        float s = 0.0f;
-        for (int c = 0; c < nchunk; ++c) s += p[(long)c * 64];           // fixed order
+        const float s = ysum[((((long)b * 4 + k) * DB + db) * nchunk) * 64 + lane];   // reduced into chunk slot 0
         acc = fmaf(gw[(4 * d + kq) * 4 + k], s * inv_L, acc);
     }
     gate[(long)b * 4 * D + e] = 1.0f / (1.0f + expf(-acc));
@@ -235,10 +262,12 @@ __global__ __launch_bounds__(256) void combine_kernel(CombArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) gk[k][i] = g[k * a.D + d];
     }
+    // 8 pixels per wave, all loads and both butterfly reductions of the 8 pixels interleaved (ILP)
+    float v[8][DV], s[8], sq[8];
+#pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int px = wave * 8 + q, p = p0 + px;
-        if (p >= a.L) break;
-        float v[DV], s = 0.0f;
+        const int p = min(p0 + wave * 8 + q, a.L - 1);
+        s[q] = 0.0f;
 #pragma unroll
         for (int i = 0; i < DV; ++i) {
             const int d = i * 64 + lane;
@@ -248,25 +277,38 @@ __global__ __launch_bounds__(256) void combine_kernel(CombArgs a) {
                 for (int k = 0; k < 4; ++k)
                     t = fmaf(a.yT[(((long)b * 4 + k) * a.L + p) * a.D + d], gk[k][i], t);
             }
-            v[i] = t;
-            s += t;
+            v[q][i] = t;
+            s[q] += t;
         }
+    }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const float mean = s / (float)a.D;
-        float sq = 0.0f;
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s[q] += __shfl_xor(s[q], o);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        s[q] /= (float)a.D;                                  // mean
+        sq[q] = 0.0f;
 #pragma unroll
         for (int i = 0; i < DV; ++i) {
-            const float dlt = (i * 64 + lane < a.D) ? v[i] - mean : 0.0f;
-            sq += dlt * dlt;
+            const float dlt = (i * 64 + lane < a.D) ? v[q][i] - s[q] : 0.0f;
+            sq[q] += dlt * dlt;
         }
+    }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-        const float rstd = 1.0f / sqrtf(sq / (float)a.D + a.eps);
+    for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-        for (int i = 0; i < DV; ++i) {
-            const int d = i * 64 + lane;
-            if (d < a.D) tile[d * 33 + px] = (v[i] - mean) * rstd * nw[i] + nb[i];
+        for (int q = 0; q < 8; ++q) sq[q] += __shfl_xor(sq[q], o);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int px = wave * 8 + q;
+        const float rstd = 1.0f / sqrtf(sq[q] / (float)a.D + a.eps);
+        if (p0 + px < a.L) {
+#pragma unroll
+            for (int i = 0; i < DV; ++i) {
+                const int d = i * 64 + lane;
+                if (d < a.D) tile[d * 33 + px] = (v[q][i] - s[q]) * rstd * nw[i] + nb[i];
+            }
         }
     }
     __syncthreads();
@@ -281,13 +323,14 @@ __global__ __launch_bounds__(256) void combine_kernel(CombArgs a) {
     }
 }
 
-extern "C" int irm_losh_combine_f32(const float* ysum, const float* gw, const float* gb, float* gate,
+extern "C" int irm_losh_combine_f32(float* ysum, const float* gw, const float* gb, float* gate,
                                     const float* yT, const float* nw, const float* nb, const float* z, long z_bs,
                                     float* out, long out_bs, int B, int L, int D, int nchunk, float eps,
                                     hipStream_t stream) {
     if (!ysum || !gw || !gb || !gate || !yT || !nw || !nb || !z || !out) return IRM_EINVAL;
     if (B <= 0 || L <= 0 || D <= 0 || nchunk <= 0 || B > 65535 || D > 1024) return IRM_EINVAL;
     const int DB = (D + 63) / 64;
+    hipLaunchKernelGGL(ysum_reduce_kernel, dim3(B * 4 * DB), dim3(256), 0, stream, ysum, nchunk);
     hipLaunchKernelGGL(gate_kernel, dim3((4 * D + 255) / 256, B), dim3(256), 0, stream, ysum, gw, gb, gate, D, DB,
                        nchunk, 1.0f / (float)L);
     CombArgs a{yT, gate, nw, nb, z, z_bs, out, out_bs, L, D, eps};

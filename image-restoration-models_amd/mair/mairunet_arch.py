@@ -224,7 +224,7 @@ class MaIRUNet(nn.Module):
         pT = self._buf("pT", B * L * 4 * J, dev).view(B, L, 4 * J)
         yT = self._buf("yT", B * 4 * L * D, dev)
         chunk, nchunk, DB = ops.scan_plan(B, L, D)
-        state = self._buf("scan_state", B * 4 * DB * nchunk * N * 64, dev)
+        state = self._buf("scan_state", 2 * B * 4 * DB * nchunk * N * 64, dev)
         sdt = self._buf("scan_sdt", B * 4 * DB * nchunk * 64, dev)
         ysum = self._buf("scan_ysum", B * 4 * DB * nchunk * 64, dev)
         gate = self._buf("gate", B * 4 * D, dev)

@@ -193,9 +193,10 @@ def transpose(src: torch.Tensor, dst: torch.Tensor, R: int, C: int):
 
 
 def scan_plan(B: int, L: int, D: int):
-    """(chunk, nchunk, DB): time steps per wave so that roughly 2 waves per SIMD exist."""
+    """(chunk, nchunk, DB): time steps per wave; a wave is one sequential recurrence, so the scan is
+    latency bound per wave - aim at ~4 waves per SIMD (4k waves) before growing the chunk."""
     DB = (D + 63) // 64
-    nchunk = max(1, min(-(-L // 32), -(-2048 // (B * 4 * DB))))
+    nchunk = max(1, min(-(-L // 32), -(-4096 // (B * 4 * DB))))
     chunk = max(32, -(-(-(-L // nchunk)) // 4) * 4)
     return chunk, -(-L // chunk), DB
 

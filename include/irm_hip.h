@@ -153,7 +153,7 @@ int irm_transpose_f32(const float* in, long in_bs, float* out, long out_bs, int 
  *     h[n] = exp(dt * A[k*D+d][n]) * h[n] + dt * pT[p][k*J + R + n] * xT[p][d]
  *     yT[k][p][d] = sum_n h[n] * pT[p][k*J + R + N + n] + Dskip[k*D+d] * xT[p][d]
  * xT [B][L][D], pT [B][L][4J] channel-last; ids [4][L] int32 (device); A = -exp(A_logs).
- * Chunked over L (chunk steps per wave): workspaces state [B][4][DB][nchunk][N][64], sdt and ysum
+ * Chunked over L (chunk steps per wave): workspaces state [2][B][4][DB][nchunk][N][64], sdt and ysum
  * [B][4][DB][nchunk][64] with DB = ceil(D/64), nchunk = ceil(L/chunk); ysum receives per-chunk sums of y
  * (for the ShuffleAttn mean).  (N, R) in {(4,3), (8,6), (16,12), (32,24)}. */
 int irm_selective_scan_f32(const float* xT, const float* pT, const int* ids, const float* dtw, const float* dtb,
@@ -162,8 +162,9 @@ int irm_selective_scan_f32(const float* xT, const float* pT, const int* ids, con
 
 /* After the scan: ShuffleAttn gate g = sigmoid(W * mean_HW(y) + b) per (direction, channel)
  * (mairunet_arch.py:21-60, :273; gw [4D][4], gb [4D]), direction sum (:274-275), out_norm LayerNorm over D
- * (:277) and * silu(z) (:278); z and out planar [B][D][L].  gate: workspace [B][4][D]. */
-int irm_losh_combine_f32(const float* ysum, const float* gw, const float* gb, float* gate, const float* yT,
+ * (:277) and * silu(z) (:278); z and out planar [B][D][L].  gate: workspace [B][4][D]; ysum (from the scan)
+ * is reduced in place into its chunk-0 slots. */
+int irm_losh_combine_f32(float* ysum, const float* gw, const float* gb, float* gate, const float* yT,
                          const float* nw, const float* nb, const float* z, long z_bs, float* out, long out_bs,
                          int B, int L, int D, int nchunk, float eps, irm_stream_t stream);
 

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from irm_amd import _hip, configs, dncnn, rednet, restormer, synth, utils
-from oracle import convnets_ref, restormer_ref, tiler_ref
+from oracle import convnets_ref, mair_ref, restormer_ref, tiler_ref
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -66,6 +66,48 @@ def test_oracle_tiler_vs_golden(golden, manifest):
     assert np.array_equal(tiler_ref.gaussian_window(64, 64, 1)[:, :, 0], golden("tiler")["window_64"])
     tl = gin("noisecheck", (40, 48, 3)).numpy()
     assert np.array_equal(tiler_ref.degrade(tl, 25), golden("tiler")["noise_40x48x3_s25"])
+
+
+def test_selective_scan_oracle_vs_independent_float64():
+    """The scan op is unpinned by any reference artefact (mamba_ssm is absent): cross-check the oracle's
+    fp32 restatement against an independent float64 evaluation written from the published recurrence."""
+    torch.manual_seed(0)
+    b, k, d, n, L = 2, 4, 5, 3, 37
+    u, dt = torch.randn(b, k * d, L), torch.randn(b, k * d, L)
+    A = -torch.rand(k * d, n) * 2 - 0.1
+    B, C = torch.randn(b, k, n, L), torch.randn(b, k, n, L)
+    D, bias = torch.randn(k * d), torch.randn(k * d)
+    y = mair_ref.selective_scan(u, dt, A, B, C, D, delta_bias=bias, delta_softplus=True)
+    ref = np.zeros((b, k * d, L))
+    for bi in range(b):
+        for r in range(k * d):
+            h = np.zeros(n)
+            for t in range(L):
+                x = float(dt[bi, r, t]) + float(bias[r])
+                dl = x if x > 20 else np.log1p(np.exp(x))
+                h = np.exp(dl * A[r].double().numpy()) * h + dl * B[bi, r // d, :, t].double().numpy() * float(u[bi, r, t])
+                ref[bi, r, t] = h @ C[bi, r // d, :, t].double().numpy() + float(D[r]) * float(u[bi, r, t])
+    assert np.abs(y.numpy() - ref).max() < 1e-4
+
+
+def test_mair_oracle_and_ids_vs_golden(golden, manifest):
+    for key in golden("mair").files:
+        if key.startswith("ids_"):
+            h, w = map(int, key.split("_")[1].split("x"))
+            sl = int(key.split("_s")[1])
+            assert np.array_equal(mair_ref.scan_ids(h, w, sl)[0].numpy(), golden("mair")[key])
+    from irm_amd.mair import mairunet_arch
+    assert np.array_equal(mairunet_arch.scan_ids(6, 10, 4, "cpu").numpy(), golden("mair")["ids_6x10_s4"])
+    shapes = {k: tuple(v) for k, v in manifest["mairunet_param_shapes"].items()}
+    from irm_amd import mair
+    assert {k: list(v.shape) for k, v in mair.MaIRUNet(
+        dim=48, num_blocks=[4, 6, 6, 8], num_refinement_blocks=4, ssm_ratio=2.0, flp_ratio=4.0, mlp_ratio=1.5,
+        scan_len=4).state_dict().items()} == manifest["mairunet_param_shapes"]
+    sd = synth.synth_state_dict(shapes, seed=42, rules=mair.SYNTH_RULES)
+    x = gin("mair_in_24x40", (1, 3, 24, 40))
+    with torch.no_grad():
+        y = mair_ref.mairunet_forward(x, sd, scan_len=4).numpy()
+    assert np.abs(y - golden("mair")["mairunet_24x40"]).max() <= 2e-5
 
 
 # --------------------------------------------------------------------------- host logic

@@ -58,7 +58,7 @@ def test_selective_scan_vs_oracle(dev, B, D, N, R, H, W, chunk):
     pT = proj.reshape(B, 4 * J, L).transpose(1, 2).contiguous().to(dev)                     # (B,L,4J)
     nchunk, DB = -(-L // chunk), -(-D // 64)
     yT = torch.full((B, 4, L, D), float("nan"), device=dev)
-    state = torch.empty(B * 4 * DB * nchunk * N * 64, device=dev)
+    state = torch.empty(2 * B * 4 * DB * nchunk * N * 64, device=dev)
     sdt = torch.empty(B * 4 * DB * nchunk * 64, device=dev)
     ysum = torch.empty(B * 4 * DB * nchunk * 64, device=dev)
     ops.selective_scan(xT, pT, ids.int().to(dev), dtw.to(dev), dtb.to(dev), A.to(dev), Ds.to(dev), yT, state, sdt, ysum,
@@ -92,9 +92,10 @@ def test_losh_combine(dev):
         ysum[:, :, 0, c, :] = part[:, :, :64]
         ysum[:, :, 1, c, :32] = part[:, :, 64:]
     gate = torch.empty(B, 4, D, device=dev)
+    ysum = ysum.to(dev)
     zg = rnd("cz", (B, D + 3, H, W)).to(dev)[:, 1:1 + D]
     out = torch.empty(B, D, H, W, device=dev)
-    ops.losh_combine(ysum.to(dev), gw.to(dev), gb.to(dev), gate, y.permute(0, 1, 3, 2).contiguous().to(dev), nw.to(dev),
+    ops.losh_combine(ysum, gw.to(dev), gb.to(dev), gate, y.permute(0, 1, 3, 2).contiguous().to(dev), nw.to(dev),
                      nb.to(dev), zg, out, B, L, D, nchunk)
     assert (gate.cpu().double() - g).abs().max() < 1e-5
     assert (out.cpu().double().reshape(B, D, L) - ref).abs().max() < 2e-4
