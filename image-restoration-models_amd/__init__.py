@@ -9,7 +9,7 @@ import sys as _sys
 
 __version__ = "0.1.0"
 
-_SRC_MODULES = ("configs", "utils", "restormer", "dncnn", "rednet", "mair")
+_SRC_MODULES = ("configs", "utils", "restormer", "dncnn", "rednet", "mair", "deblurganv2")
 
 
 def install_as_src():

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libirm_hip.so")
 
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU, ACT_RELU6 = 0, 1, 2, 3, 4
 LN_NONE, LN_WITHBIAS, LN_BIASFREE = 0, 1, 2
 
 _P, _L, _I, _F = C.c_void_p, C.c_long, C.c_int, C.c_float
@@ -29,7 +29,12 @@ SIGNATURES = {
     "irm_mdta_gram_f32": [_P, _L, _P, _I, _I, _I, _I, _I, _P],
     "irm_mdta_finalize_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "irm_conv3x3_f32": [_P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "irm_tile_extract": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P],
+    "irm_tile_extract": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
+    "irm_chan_stats_f32": [_P, _L, _P, _I, _I, _I, _F, _P],
+    "irm_chan_norm_act_f32": [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P],
+    "irm_conv3x3_s2_f32": [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _P],
+    "irm_dwconv3x3_s2_f32": [_P, _L, _P, _P, _L, _I, _I, _I, _I, _P],
+    "irm_upsample_add_f32": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
     "irm_transpose_f32": [_P, _L, _P, _L, _I, _I, _I, _P],
     "irm_selective_scan_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "irm_losh_combine_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P],

@@ -26,6 +26,12 @@
 #define CV_TWP 40
 #define CV_PLANE (CV_ROWS * CV_TWP)   // 400
 
+__device__ __forceinline__ float cv_res(float v, float r, int mode) {
+    if (mode == 1) return v + r;
+    if (mode == 2) return r - v;
+    return fminf(fmaxf(tanhf(v) + r, -1.0f), 1.0f);      // DeblurGANv2 output: fpn_mobilenet.py:68-70
+}
+
 struct ConvArgs {
     const float* Wp;              // packed [9][mtiles][ksteps][64]
     const float* X; long x_bs;    // [B][Ci][H][W]
@@ -35,7 +41,7 @@ struct ConvArgs {
     int Ci, Co, H, W;
     int mtiles, ksteps;           // ceil(Co/16), 2*ceil(Ci/8)
     int relu1;                    // relu right after bias
-    int res_mode;                 // 0 none, 1: v += R, 2: v = R - v
+    int res_mode;                 // 0 none, 1: v += R, 2: v = R - v, 3: v = clamp(tanh(v) + R, -1, 1)
     int relu2;                    // relu after the residual
     int store_mode;               // 0 NCHW, 1 PixelUnshuffle(2), 2 PixelShuffle(2)
     int tiles_x;
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
                                 const float4 rr = *reinterpret_cast<const float4*>(R + off);
                                 const float rv[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = a.res_mode == 1 ? v[e] + rv[e] : rv[e] - v[e];
+                                for (int e = 0; e < 4; ++e) v[e] = cv_res(v[e], rv[e], a.res_mode);
                             }
                             if (a.relu2) {
 #pragma unroll
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
                             for (int e = 0; e < 4; ++e) {
                                 if (x + e < a.W) {
                                     float t = v[e];
-                                    if (a.res_mode) t = a.res_mode == 1 ? t + R[off + e] : R[off + e] - t;
+                                    if (a.res_mode) t = cv_res(t, R[off + e], a.res_mode);
                                     if (a.relu2) t = fmaxf(t, 0.0f);
                                     Y[off + e] = t;
                                 }
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(ConvArgs a) {
                             const float4 rr = *reinterpret_cast<const float4*>(R + off);
                             const float rv[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = a.res_mode == 1 ? v[e] + rv[e] : rv[e] - v[e];
+                            for (int e = 0; e < 4; ++e) v[e] = cv_res(v[e], rv[e], a.res_mode);
                         }
                         if (a.relu2) {
 #pragma unroll
@@ -408,7 +414,7 @@ extern "C" int irm_conv3x3_f32(const float* wp, const float* x, long x_bs, float
                                int res_mode, int relu2, int store_mode, int ct, int ygroups,
                                hipStream_t stream) {
     if (!wp || !x || !y || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return IRM_EINVAL;
-    if (res_mode < 0 || res_mode > 2 || (res_mode && !res) || store_mode < 0 || store_mode > 2) return IRM_EINVAL;
+    if (res_mode < 0 || res_mode > 3 || (res_mode && !res) || store_mode < 0 || store_mode > 2) return IRM_EINVAL;
     if (store_mode != 0 && res_mode != 0) return IRM_EINVAL;
     if (store_mode == 1 && ((H & 1) || (W & 1))) return IRM_EINVAL;
     if (store_mode == 2 && (Co & 3)) return IRM_EINVAL;

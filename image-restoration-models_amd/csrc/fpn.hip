@@ -1,0 +1,189 @@
+// DeblurGANv2 FPN-MobileNet support kernels (src/deblurganv2/models/mobilenet_v2.py:5-57,
+// models/fpn_mobilenet.py:53-70, 121-146).  The generator runs in train mode in the reference
+// (src/deblurganv2/__init__.py:38) on one tile at a time, so every BatchNorm2d / InstanceNorm2d is a
+// per-(sample, channel) normalisation over H x W with the biased variance: irm_chan_stats_f32 +
+// irm_chan_norm_act_f32.  The remaining pieces are the stride-2 stem conv, the stride-2 depth-wise conv
+// and nearest-neighbour up-sampling (+ lateral add).  All HBM-bound, planar NCHW.
+#include "irm_common.h"
+
+#define IRM_ACT_RELU6 4
+
+// ---------------------------------------------------------------------------
+// per (b, c) plane: mean and 1/sqrt(biased var + eps); two passes (mean, then centred squares; the
+// second pass re-reads the plane from L2), fixed-order block reduction.
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+__global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ st,
+                                                         int C, int N, float eps) {
+    __shared__ float sh[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float* p = x + (long)b * x_bs + (long)c * N;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < N; i += 256) s += p[i];
+    const float mean = block_sum256(s, sh) / (float)N;
+    float q = 0.0f;
+    for (int i = threadIdx.x; i < N; i += 256) { const float d = p[i] - mean; q += d * d; }
+    const float var = block_sum256(q, sh) / (float)N;
+    if (threadIdx.x == 0) {
+        st[((long)b * C + c) * 2] = mean;
+        st[((long)b * C + c) * 2 + 1] = 1.0f / sqrtf(var + eps);
+    }
+}
+
+extern "C" int irm_chan_stats_f32(const float* x, long x_bs, float* stats, int B, int C, int N, float eps,
+                                  hipStream_t stream) {
+    if (!x || !stats || B <= 0 || C <= 0 || N <= 0 || B > 65535) return IRM_EINVAL;
+    hipLaunchKernelGGL(chan_stats_kernel, dim3(C, B), dim3(256), 0, stream, x, x_bs, stats, C, N, eps);
+    return irm_launch_status();
+}
+
+// y = act((x - mean) * rstd * w[c] + b[c]) (+ res); w, b optional (InstanceNorm2d(affine=False)); in place ok
+__global__ __launch_bounds__(256) void chan_norm_act_kernel(const float* __restrict__ x, long x_bs,
+                                                            const float* __restrict__ st, const float* __restrict__ w,
+                                                            const float* __restrict__ bi, const float* __restrict__ res,
+                                                            long r_bs, float* __restrict__ y, long y_bs, int C, int N,
+                                                            int act) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float mean = st[((long)b * C + c) * 2], rstd = st[((long)b * C + c) * 2 + 1];
+    const float g = w ? w[c] : 1.0f, be = bi ? bi[c] : 0.0f;
+    const long off = (long)c * N;
+    const float* xp = x + (long)b * x_bs + off;
+    const float* rp = res ? res + (long)b * r_bs + off : nullptr;
+    float* yp = y + (long)b * y_bs + off;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        float v = (xp[i] - mean) * rstd * g + be;
+        if (act == IRM_ACT_RELU) v = fmaxf(v, 0.0f);
+        else if (act == IRM_ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);
+        if (rp) v += rp[i];
+        yp[i] = v;
+    }
+}
+
+extern "C" int irm_chan_norm_act_f32(const float* x, long x_bs, const float* stats, const float* w, const float* b,
+                                     const float* res, long r_bs, float* y, long y_bs, int B, int C, int N, int act,
+                                     hipStream_t stream) {
+    if (!x || !stats || !y || B <= 0 || C <= 0 || N <= 0 || B > 65535 || C > 65535) return IRM_EINVAL;
+    if (act != IRM_ACT_NONE && act != IRM_ACT_RELU && act != IRM_ACT_RELU6) return IRM_EINVAL;
+    int gx = (N + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(chan_norm_act_kernel, dim3(gx, C, B), dim3(256), 0, stream, x, x_bs, stats, w, b, res, r_bs, y,
+                       y_bs, C, N, act);
+    return irm_launch_status();
+}
+
+// ---------------------------------------------------------------------------
+// dense 3x3, stride 2, zero pad 1, no bias, small Ci (the MobileNetV2 stem conv_bn(3, 32, 2),
+// mobilenet_v2.py:5-10).  One thread = one output pixel x 8 output channels.
+__global__ __launch_bounds__(256) void conv3x3_s2_kernel(const float* __restrict__ x, long x_bs,
+                                                         const float* __restrict__ w, float* __restrict__ y, long y_bs,
+                                                         int Ci, int Co, int H, int W, int Ho, int Wo) {
+    const int b = blockIdx.z, cg = blockIdx.y;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= Ho * Wo) return;
+    const int oy = o / Wo, ox = o % Wo;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    const float* xp = x + (long)b * x_bs;
+    for (int ci = 0; ci < Ci; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if (ix < 0 || ix >= W) continue;
+                const float v = xp[((long)ci * H + iy) * W + ix];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int co = cg * 8 + j;
+                    if (co < Co) acc[j] = fmaf(v, w[(((long)co * Ci + ci) * 3 + ky) * 3 + kx], acc[j]);
+                }
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int co = cg * 8 + j;
+        if (co < Co) y[(long)b * y_bs + ((long)co * Ho + oy) * Wo + ox] = acc[j];
+    }
+}
+
+extern "C" int irm_conv3x3_s2_f32(const float* x, long x_bs, const float* w, float* y, long y_bs, int B, int Ci, int Co,
+                                  int H, int W, hipStream_t stream) {
+    if (!x || !w || !y || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || B > 65535) return IRM_EINVAL;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;          // floor((H + 2 - 3) / 2) + 1
+    dim3 grid((Ho * Wo + 255) / 256, (Co + 7) / 8, B);
+    hipLaunchKernelGGL(conv3x3_s2_kernel, grid, dim3(256), 0, stream, x, x_bs, w, y, y_bs, Ci, Co, H, W, Ho, Wo);
+    return irm_launch_status();
+}
+
+// depth-wise 3x3, stride 2, zero pad 1, no bias (InvertedResidual dw, mobilenet_v2.py:32-46)
+__global__ __launch_bounds__(256) void dwconv3x3_s2_kernel(const float* __restrict__ x, long x_bs,
+                                                           const float* __restrict__ w, float* __restrict__ y, long y_bs,
+                                                           int H, int W, int Ho, int Wo) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= Ho * Wo) return;
+    const int oy = o / Wo, ox = o % Wo;
+    const float* xp = x + (long)b * x_bs + (long)c * H * W;
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = w[c * 9 + i];
+    float acc = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            if (ix < 0 || ix >= W) continue;
+            acc = fmaf(xp[(long)iy * W + ix], k[ky * 3 + kx], acc);
+        }
+    }
+    y[(long)b * y_bs + ((long)c * Ho + oy) * Wo + ox] = acc;
+}
+
+extern "C" int irm_dwconv3x3_s2_f32(const float* x, long x_bs, const float* w, float* y, long y_bs, int B, int C, int H,
+                                    int W, hipStream_t stream) {
+    if (!x || !w || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || B > 65535 || C > 65535) return IRM_EINVAL;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    dim3 grid((Ho * Wo + 255) / 256, C, B);
+    hipLaunchKernelGGL(dwconv3x3_s2_kernel, grid, dim3(256), 0, stream, x, x_bs, w, y, y_bs, H, W, Ho, Wo);
+    return irm_launch_status();
+}
+
+// out[b][c][y][x] = (add ? add[b][c][y][x] : 0) + src[b][c][y / s][x / s]     (nearest, integer scale s)
+__global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restrict__ src, long s_bs,
+                                                           const float* __restrict__ add, long a_bs,
+                                                           float* __restrict__ out, long o_bs, int Hs, int Ws, int s) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int Ho = Hs * s, Wo = Ws * s;
+    const float* sp = src + (long)b * s_bs + (long)c * Hs * Ws;
+    const float* ap = add ? add + (long)b * a_bs + (long)c * Ho * Wo : nullptr;
+    float* op = out + (long)b * o_bs + (long)c * Ho * Wo;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Ho * Wo; i += gridDim.x * 256) {
+        const int y = i / Wo, x = i % Wo;
+        const float v = sp[(long)(y / s) * Ws + x / s];
+        op[i] = ap ? ap[i] + v : v;
+    }
+}
+
+extern "C" int irm_upsample_add_f32(const float* src, long s_bs, const float* add, long a_bs, float* out, long o_bs,
+                                    int B, int C, int Hs, int Ws, int scale, hipStream_t stream) {
+    if (!src || !out || B <= 0 || C <= 0 || Hs <= 0 || Ws <= 0 || scale <= 0 || B > 65535 || C > 65535) return IRM_EINVAL;
+    int gx = (Hs * Ws * scale * scale + 255) / 256;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(gx, C, B), dim3(256), 0, stream, src, s_bs, add, a_bs, out, o_bs, Hs, Ws,
+                       scale);
+    return irm_launch_status();
+}

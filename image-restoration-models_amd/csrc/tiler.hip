@@ -14,7 +14,8 @@ struct ExtractArgs {
     int H, W, C, th, tw, ph, pw, T;
     int is_u16;
     float scale;           // 255 or 65535
-    float mean, inv_std;   // optional (x - mean) * inv_std after scaling (DeblurGANv2); 0,1 = off
+    float mean, inv_std;   // DeblurGANv2 normalize: v = (raw - mean) * inv_std on the RAW integer value; 0,1 = off
+    int pad_zero;          // 0: reflect pad (utils.pad), 1: zero pad (deblurganv2.pad)
 };
 
 __global__ __launch_bounds__(256) void tile_extract_kernel(ExtractArgs a) {
@@ -26,6 +27,10 @@ __global__ __launch_bounds__(256) void tile_extract_kernel(ExtractArgs a) {
     const int py = (int)(t % a.ph); t /= a.ph;
     const int c = (int)(t % a.C);
     const int tile = (int)(t / a.C);
+    if (a.pad_zero && (py >= a.th || px >= a.tw)) {          // deblurganv2/__init__.py:16-24
+        a.tiles[idx] = 0.0f;
+        return;
+    }
     // reflect (no edge repeat) for the padded rows/cols: utils.py:174-181
     const int sy = py < a.th ? py : 2 * a.th - 2 - py;
     const int sx = px < a.tw ? px : 2 * a.tw - 2 - px;
@@ -33,23 +38,24 @@ __global__ __launch_bounds__(256) void tile_extract_kernel(ExtractArgs a) {
     const long src = ((long)gy * a.W + gx) * a.C + c;
     const float raw = a.is_u16 ? (float)reinterpret_cast<const unsigned short*>(a.img)[src]
                                : (float)reinterpret_cast<const unsigned char*>(a.img)[src];
-    float v = __fdiv_rn(raw, a.scale);                      // utils.py:159-171
+    const bool albu = a.inv_std != 1.0f || a.mean != 0.0f;
+    // utils.py:159-171, or albumentations Normalize (aug.py:31-39): (x - mean*255) * (1 / (std*255))
+    float v = albu ? __fmul_rn(__fsub_rn(raw, a.mean), a.inv_std) : __fdiv_rn(raw, a.scale);
     if (a.noise) {                                          // utils.py:29-36
         const double d = (double)v + a.noise[((long)sy * a.tw + sx) * a.C + c];
         v = (float)fmin(fmax(d, 0.0), 1.0);
     }
-    if (a.inv_std != 1.0f || a.mean != 0.0f) v = __fmul_rn(__fsub_rn(v, a.mean), a.inv_std);
     a.tiles[idx] = v;
 }
 
 extern "C" int irm_tile_extract(const void* img, int is_u16, const int* origins, const double* noise,
                                 float* tiles, int H, int W, int C, int th, int tw, int ph, int pw, int T,
-                                float mean, float inv_std, hipStream_t stream) {
+                                float mean, float inv_std, int pad_zero, hipStream_t stream) {
     if (!img || !origins || !tiles || H <= 0 || W <= 0 || C <= 0 || T <= 0) return IRM_EINVAL;
     if (th <= 0 || tw <= 0 || ph < th || pw < tw || th > H || tw > W) return IRM_EINVAL;
-    if (ph - th >= th || pw - tw >= tw) return IRM_EINVAL;    // reflect needs pad < extent
+    if (!pad_zero && (ph - th >= th || pw - tw >= tw)) return IRM_EINVAL;    // reflect needs pad < extent
     ExtractArgs a{img, origins, noise, tiles, H, W, C, th, tw, ph, pw, T, is_u16,
-                  is_u16 ? 65535.0f : 255.0f, mean, inv_std};
+                  is_u16 ? 65535.0f : 255.0f, mean, inv_std, pad_zero};
     const long total = (long)T * C * ph * pw;
     hipLaunchKernelGGL(tile_extract_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
     return irm_launch_status();

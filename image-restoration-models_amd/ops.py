@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 
 from . import _hip
-from ._hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU, LN_BIASFREE, LN_NONE, LN_WITHBIAS  # noqa: F401
+from ._hip import ACT_GELU, ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SILU, LN_BIASFREE, LN_NONE, LN_WITHBIAS  # noqa: F401
 
 
 class KernelTimer:
@@ -216,3 +216,44 @@ def losh_combine(ysum, gw, gb, gate, yT, nw, nb, z, out, B, L, D, nchunk, eps=1e
     _launch("losh_combine", 12.0 * B * L * D, 4.0 * B * L * D * 6, "irm_losh_combine_f32", _hip.ptr(ysum), _hip.ptr(gw),
             _hip.ptr(gb), _hip.ptr(gate), _hip.ptr(yT), _hip.ptr(nw), _hip.ptr(nb), _hip.ptr(z), _bs(z), _hip.ptr(out),
             _bs(out), B, L, D, nchunk, float(eps), tag=f"L{L} D{D} B{B}")
+
+
+# --------------------------------------------------------------------------- DeblurGANv2 FPN-MobileNet
+def chan_stats(x, stats, eps=1e-5):
+    """stats[b, c] = (mean, rstd) over H*W (train-mode BatchNorm on one tile / InstanceNorm)."""
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    _launch("chan_stats", 4.0 * B * C * H * W, 4.0 * B * C * H * W, "irm_chan_stats_f32", _hip.ptr(x), _bs(x),
+            _hip.ptr(stats), B, C, H * W, float(eps), tag=f"C{C} {H}x{W} B{B}")
+
+
+def chan_norm_act(x, stats, y, *, weight=None, bias=None, res=None, act=ACT_NONE):
+    _chk(x, "x"), _chk(y, "y")
+    B, C, H, W = x.shape
+    _launch("chan_norm_act", 4.0 * B * C * H * W, 4.0 * B * C * H * W * (3 if res is not None else 2),
+            "irm_chan_norm_act_f32", _hip.ptr(x), _bs(x), _hip.ptr(stats), _hip.ptr(weight), _hip.ptr(bias),
+            _hip.ptr(res), _bs(res), _hip.ptr(y), _bs(y), B, C, H * W, int(act), tag=f"C{C} {H}x{W} B{B}")
+
+
+def conv3x3_s2(x, w, y, ci, co):
+    _chk(x, "x"), _chk(y, "y")
+    B, _, H, W = x.shape
+    _launch("conv3x3_s2", 18.0 * B * ci * co * (H // 2) * (W // 2), 4.0 * B * (ci * H * W + co * H * W / 4),
+            "irm_conv3x3_s2_f32", _hip.ptr(x), _bs(x), _hip.ptr(w), _hip.ptr(y), _bs(y), B, ci, co, H, W,
+            tag=f"ci{ci} co{co} {H}x{W} B{B}")
+
+
+def dwconv3x3_s2(x, w9, y):
+    _chk(x, "x"), _chk(y, "y")
+    B, C, H, W = x.shape
+    _launch("dwconv3x3_s2", 18.0 * B * C * H * W / 4, 5.0 * B * C * H * W, "irm_dwconv3x3_s2_f32", _hip.ptr(x), _bs(x),
+            _hip.ptr(w9), _hip.ptr(y), _bs(y), B, C, H, W, tag=f"C{C} {H}x{W} B{B}")
+
+
+def upsample_add(src, out, scale, add=None):
+    """out = (add or 0) + nearest-upsample(src, scale)."""
+    _chk(src, "src"), _chk(out, "out")
+    B, C, Hs, Ws = src.shape
+    _launch("upsample_add", 0.0, 4.0 * B * C * Hs * Ws * (1 + scale * scale * (2 if add is not None else 1)),
+            "irm_upsample_add_f32", _hip.ptr(src), _bs(src), _hip.ptr(add), _bs(add), _hip.ptr(out), _bs(out), B, C, Hs, Ws,
+            int(scale), tag=f"C{C} {Hs}x{Ws} x{scale} B{B}")

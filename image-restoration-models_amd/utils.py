@@ -18,12 +18,13 @@ import numpy as np
 import torch
 from torch.nn import Module
 
-from . import _hip, dncnn, mair, rednet, restormer
+from . import _hip, deblurganv2, dncnn, mair, rednet, restormer
 from .configs import PATCH_CONFIG, ROOT_RESULTS_DIR, ROOT_WEIGHTS_DIR
 from .dncnn import DnCNN
 from .rednet import REDNet
 from .restormer import Restormer
 from .mair import MaIRUNet
+from .deblurganv2 import FPNMobileNet
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -133,7 +134,11 @@ def get_model_instance(task, subtask, model_name, device: torch.device, gray=Fal
         if task == 'deblurring' and subtask == 'motion':
             return mair.get_model(os.path.join(opt_dir, 'test_MaIR_MotionDeblur.yml'))
     elif model_key == 'DeblurGANv2':
-        raise NotImplementedError('DeblurGANv2 is not built yet in the MI355X path (see DESIGN.md scope table)')
+        if task == 'deblurring' and subtask == 'motion':
+            if 'Inception' in model_name:
+                return deblurganv2.get_model(f'{ROOT_WEIGHTS_DIR}/DeblurGANv2/fpn_inception.h5', device)
+            if 'MobileNet' in model_name:
+                return deblurganv2.get_model(f'{ROOT_WEIGHTS_DIR}/DeblurGANv2/fpn_mobilenet.h5', device)
     raise ValueError('No model instance found for current configuration.')
 
 
@@ -211,12 +216,19 @@ def _window_on(device, ps: int) -> torch.Tensor:
 
 def tiled_forward_device(model: Module, img_dev: torch.Tensor, patch_size, patch_overlap, pad8: bool,
                          noise_sigma=None, target_dev: torch.Tensor | None = None, max_batch: int = 8,
-                         keep_tiles: list | None = None):
+                         keep_tiles: list | None = None, hooks: str | None = None):
     """Device pipeline for one uint8/uint16 HWC image already on the GPU.
 
     Returns (out uint8/uint16 HWC device tensor, sse device tensor or None).
-    Nothing here synchronises with the host.
+    Nothing here synchronises with the host.  hooks="deblurganv2" selects that model's normalize / pad /
+    postprocess (src/deblurganv2/__init__.py:11-28) instead of /255 and the reflect pad to 8.
     """
+    norm_mean, norm_inv_std, post_scale, post_shift = 0.0, 1.0, 1.0, 0.0
+    pad_mode = "reflect8" if pad8 else "none"
+    if hooks == "deblurganv2":
+        norm_mean = float(np.float32(0.5) * np.float32(255.0))
+        norm_inv_std = float(np.float32(1.0) / (np.float32(0.5) * np.float32(255.0)))
+        post_scale, post_shift, pad_mode = 0.5, 1.0, "zero32"
     h, w, c = img_dev.shape
     is_u16 = img_dev.dtype in (torch.uint16, torch.int16)
     dev = img_dev.device
@@ -226,9 +238,11 @@ def tiled_forward_device(model: Module, img_dev: torch.Tensor, patch_size, patch
     else:
         ps, ys, xs = max(h, w), [0], [0]
     th, tw = min(ps, h), min(ps, w)
-    if pad8:
+    if pad_mode == "reflect8":
         ph = (th // 8 + 1) * 8 if th % 8 else th
         pw = (tw // 8 + 1) * 8 if tw % 8 else tw
+    elif pad_mode == "zero32":
+        ph, pw = (th // 32 + 1) * 32, (tw // 32 + 1) * 32
     else:
         ph, pw = th, tw
     origins = [(y0, x0) for y0 in ys for x0 in xs]
@@ -240,7 +254,7 @@ def tiled_forward_device(model: Module, img_dev: torch.Tensor, patch_size, patch
         noise = torch.from_numpy(np.random.normal(0, noise_sigma / 255., (th, tw, c))).to(dev)
     tiles = torch.empty(T, c, ph, pw, dtype=torch.float32, device=dev)
     _hip.call("irm_tile_extract", _hip.ptr(img_dev), int(is_u16), _hip.ptr(org), _hip.ptr(noise),
-              _hip.ptr(tiles), h, w, c, th, tw, ph, pw, T, 0.0, 1.0)
+              _hip.ptr(tiles), h, w, c, th, tw, ph, pw, T, float(norm_mean), float(norm_inv_std), int(pad_mode == "zero32"))
     c_out = min(3, c)
     pred = None
     nstreams = min(int(getattr(model, "num_streams", 1)), T)
@@ -282,7 +296,7 @@ def tiled_forward_device(model: Module, img_dev: torch.Tensor, patch_size, patch
         sse = torch.zeros(1, dtype=torch.int64, device=dev)
     _hip.call("irm_window_blend", _hip.ptr(pred), _hip.ptr(org), _hip.ptr(_window_on(dev, ps)), _hip.ptr(out),
               int(is_u16), _hip.ptr(target_dev), _hip.ptr(sse), h, w, c_out, pred.shape[1], th, tw,
-              pred.shape[2], pred.shape[3], ps, T, 1.0, 0.0)
+              pred.shape[2], pred.shape[3], ps, T, post_scale, post_shift)
     return out, sse
 
 
@@ -297,8 +311,10 @@ def run_model_inference(model: Module, input_img: np.ndarray, device: torch.devi
     with the reference's host-side blend - the model forward is the HIP path
     in both."""
     start_time = time.time()
-    stock = (normalize is globals()['normalize'] and (pad is None or pad is globals()['pad'])
-             and postprocess is None and input_img.dtype in (np.uint8, np.uint16))
+    dg = (normalize is deblurganv2.normalize and pad is deblurganv2.pad and postprocess is deblurganv2.postprocess
+          and input_img.dtype == np.uint8)
+    stock = dg or (normalize is globals()['normalize'] and (pad is None or pad is globals()['pad'])
+                   and postprocess is None and input_img.dtype in (np.uint8, np.uint16))
     with torch.no_grad():
         if stock:
             dev = torch.device(device)
@@ -306,7 +322,8 @@ def run_model_inference(model: Module, input_img: np.ndarray, device: torch.devi
             img_dev = torch.from_numpy(np.ascontiguousarray(src)).to(dev)
             sigma = noise_level if (need_degradation and noise_level is not None) else None
             out, _ = tiled_forward_device(model, img_dev, patch_size, patch_overlap, pad is not None, sigma,
-                                          max_batch=getattr(model, 'max_tiles_per_batch', 8))
+                                          max_batch=getattr(model, 'max_tiles_per_batch', 8),
+                                          hooks="deblurganv2" if dg else None)
             output_img = out.cpu().numpy()
             if input_img.dtype == np.uint16:
                 output_img = output_img.view(np.uint16)
@@ -361,6 +378,9 @@ def get_model_prediction(model: Module, input_image: np.ndarray, device: torch.d
     """src/utils.py:270-311: dispatch on the model class (reflect-pad-to-8 models vs plain)."""
     kw = dict(patch_size=patch_size, patch_overlap=patch_overlap, need_degradation=need_degradation,
               noise_level=noise_level, progress_bar=progress_bar)
+    if isinstance(model, (FPNMobileNet,)):                      # utils.py:280-291
+        return run_model_inference(model, input_image, device, normalize=deblurganv2.normalize, pad=deblurganv2.pad,
+                                   postprocess=deblurganv2.postprocess, **kw)
     if isinstance(model, _PAD8_MODELS):
         return run_model_inference(model, input_image, device, pad=pad, **kw)
     return run_model_inference(model, input_image, device, **kw)

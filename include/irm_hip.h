@@ -110,7 +110,8 @@ int irm_mdta_finalize_f32(const float* part, float* gsum, const float* temperatu
 
 /* Dense 3x3 convolution, stride 1, zero pad 1, implicit GEMM on the f32 MFMA:
  *   v = conv(x)[co] + bias[co]; if relu1: v = max(v,0);
- *   res_mode 1: v += res; res_mode 2: v = res - v; if relu2: v = max(v,0);
+ *   res_mode 1: v += res; res_mode 2: v = res - v; 3: v = clamp(tanh(v) + res, -1, 1)
+ *   (DeblurGANv2 output, fpn_mobilenet.py:68-70); if relu2: v = max(v,0);
  * store_mode 0: y[b][co][h][w]; 1: PixelUnshuffle(2) -> [4Co][H/2][W/2];
  * 2: PixelShuffle(2) -> [Co/4][2H][2W].
  * Replaces OverlapPatchEmbed / Downsample / Upsample / output (+ inp_img) of
@@ -125,11 +126,14 @@ int irm_conv3x3_f32(const float* wp, const float* x, long x_bs, float* y, long y
  * img [H][W][C] uint8 (is_u16=0) or uint16 -> tiles [T][C][ph][pw] float32 =
  * img/255 (or /65535), + optional float64 noise field [th][tw][C] then clip
  * to [0,1] (add_gaussian_noise, utils.py:29-36; the field is generated on the
- * host with the reference's seed), then (v-mean)*inv_std (DeblurGANv2
- * normalize; pass 0,1 to disable), reflect-padded from (th,tw) to (ph,pw)
- * (utils.pad, utils.py:174-181).  origins: [T][2] int32 (y0,x0). */
+ * host with the reference's seed); with (mean, inv_std) != (0, 1) the value is
+ * instead (raw - mean) * inv_std on the raw integer (DeblurGANv2 normalize =
+ * albumentations Normalize, aug.py:31-39: mean 127.5, inv_std 1/127.5); padded
+ * from (th,tw) to (ph,pw) by reflection (utils.pad, utils.py:174-181) or, with
+ * pad_zero, by zeros (deblurganv2.pad, __init__.py:16-24).  origins: [T][2]
+ * int32 (y0,x0). */
 int irm_tile_extract(const void* img, int is_u16, const int* origins, const double* noise, float* tiles, int H,
-                     int W, int C, int th, int tw, int ph, int pw, int T, float mean, float inv_std,
+                     int W, int C, int th, int tw, int ph, int pw, int T, float mean, float inv_std, int pad_zero,
                      irm_stream_t stream);
 
 /* Gaussian-window blend + normalise + requantise (src/utils.py:427-450) with the
@@ -140,6 +144,26 @@ int irm_tile_extract(const void* img, int is_u16, const int* origins, const doub
 int irm_window_blend(const float* pred, const int* origins, const float* window, void* out, int is_u16,
                      const void* target, unsigned long long* sse, int H, int W, int Co, int Cp, int th, int tw,
                      int ph, int pw, int ps, int T, float post_scale, float post_shift, irm_stream_t stream);
+
+/* --- DeblurGANv2 FPN-MobileNet (train-mode norms = per-(sample, channel) statistics) ---
+ * stats[b][c] = {mean, 1/sqrt(biased var + eps)} over the H*W plane: BatchNorm2d in train mode on one
+ * tile (mobilenet_v2.py:5-57 with deblurganv2/__init__.py:38) and InstanceNorm2d (fpn_mobilenet.py:96-104). */
+int irm_chan_stats_f32(const float* x, long x_bs, float* stats, int B, int C, int N, float eps, irm_stream_t stream);
+/* y = act((x - mean) * rstd * w[c] + b[c]) (+ res); w, b may be NULL (affine=False); act 0 none, 1 ReLU,
+ * 4 ReLU6; in place allowed.  The residual is the InvertedResidual skip (mobilenet_v2.py:52-56). */
+int irm_chan_norm_act_f32(const float* x, long x_bs, const float* stats, const float* w, const float* b,
+                          const float* res, long r_bs, float* y, long y_bs, int B, int C, int N, int act,
+                          irm_stream_t stream);
+/* Stem conv: dense 3x3, stride 2, pad 1, no bias; w [Co][Ci][3][3]; out ceil(H/2) x ceil(W/2). */
+int irm_conv3x3_s2_f32(const float* x, long x_bs, const float* w, float* y, long y_bs, int B, int Ci, int Co, int H,
+                       int W, irm_stream_t stream);
+/* Depth-wise 3x3, stride 2, pad 1, no bias; w [C][9]. */
+int irm_dwconv3x3_s2_f32(const float* x, long x_bs, const float* w, float* y, long y_bs, int B, int C, int H, int W,
+                         irm_stream_t stream);
+/* out = (add ? add : 0) + nearest_upsample(src, scale)  (F.interpolate(mode="nearest"), fpn_mobilenet.py:57-66,
+ * 141-145); src [B][C][Hs][Ws], out/add [B][C][Hs*scale][Ws*scale]. */
+int irm_upsample_add_f32(const float* src, long s_bs, const float* add, long a_bs, float* out, long o_bs, int B, int C,
+                         int Hs, int Ws, int scale, irm_stream_t stream);
 
 /* [B][R][C] -> [B][C][R] (planar NCHW <-> channel-last tokens around the selective scan). */
 int irm_transpose_f32(const float* in, long in_bs, float* out, long out_bs, int B, int R, int C,

@@ -14,7 +14,7 @@ What it does
      the max-abs differences in tests/golden/MANIFEST.json;
   3. stores the REFERENCE outputs (not the oracle's) as golden vectors.
 
-Usage: python oracle/gen_golden.py [--only restormer|tiler|convnets|ops|mair]
+Usage: python oracle/gen_golden.py [--only restormer|tiler|convnets|ops|deblurgan|mair]
 """
 from __future__ import annotations
 
@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 import irm_amd  # noqa: E402
 from irm_amd import synth  # noqa: E402
-from oracle import convnets_ref, mair_ref, restormer_ref, tiler_ref  # noqa: E402
+from oracle import convnets_ref, deblurgan_ref, mair_ref, restormer_ref, tiler_ref  # noqa: E402
 
 torch.manual_seed(0)
 torch.set_grad_enabled(False)
@@ -385,6 +385,46 @@ def gen_mair(ref, manifest):
     np.savez_compressed(os.path.join(GOLD, "mair.npz"), **out)
 
 
+def gen_deblurgan(ref, manifest):
+    """FPNMobileNet: the reference's own fpn_mobilenet.py / mobilenet_v2.py (torch only) imported under a
+    stub `deblurganv2` package (its __init__ needs albumentations), run in train mode like the reference."""
+    import functools
+    import importlib
+    import torch.nn as nn
+    from irm_amd.deblurganv2 import SYNTH_RULES as DG_RULES
+    base = "/root/reference/src/deblurganv2"
+    for k in [k for k in sys.modules if k == "deblurganv2" or k.startswith("deblurganv2.")]:
+        del sys.modules[k]
+    for name, path in (("deblurganv2", base), ("deblurganv2.models", base + "/models")):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        sys.modules[name] = m
+    fm = importlib.import_module("deblurganv2.models.fpn_mobilenet")
+    norm = functools.partial(nn.InstanceNorm2d, affine=False, track_running_stats=True)     # networks.py:22
+    net = fm.FPNMobileNet(norm_layer=norm, pretrained=False)
+    net.train(True)                                                                          # __init__.py:38
+    # fpn.enc0..enc4 are nn.Sequential views of fpn.features[...] (fpn_mobilenet.py:90-94): the same
+    # tensors appear under two names; synthetic values are generated for the canonical names only
+    params = {k: tuple(v.shape) for k, v in net.state_dict().items()
+              if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked")
+                      or k.startswith("fpn.enc"))}
+    manifest["fpn_mobilenet_param_shapes"] = {k: list(v) for k, v in params.items()}
+    manifest["fpn_mobilenet_state_keys"] = sorted(net.state_dict().keys())
+    sd = synth.synth_state_dict(params, seed=42, rules=DG_RULES)
+    net.load_state_dict(sd, strict=False)
+    out = {}
+    for (h, w) in [(64, 64), (96, 160)]:
+        x = synth_input(f"dg_in_{h}x{w}", (1, 3, h, w), -1.0, 1.0)
+        y_ref = net(x)
+        y_orc = deblurgan_ref.fpn_mobilenet_forward(x, sd)
+        d = maxabs(y_ref, y_orc)
+        manifest.setdefault("oracle_vs_reference", {})[f"fpn_mobilenet/{h}x{w}"] = d
+        print(f"fpn_mobilenet {h}x{w}: oracle-vs-reference {d:.3e} |y-x| mean {float((y_ref - x).abs().mean()):.4f}")
+        assert d <= 2e-5
+        out[f"fpn_mobilenet_{h}x{w}"] = y_ref.detach().numpy()
+    np.savez_compressed(os.path.join(GOLD, "deblurgan.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -394,7 +434,7 @@ def main():
     manifest = json.load(open(mpath)) if os.path.exists(mpath) else {}
     ref = import_reference()
     steps = {"ops": gen_ops, "restormer": gen_restormer, "convnets": gen_convnets, "tiler": gen_tiler,
-             "mair": gen_mair}      # mair last: it re-stubs the `mair` package for the reference's arch file
+             "deblurgan": gen_deblurgan, "mair": gen_mair}      # mair last: it re-stubs the `mair` package for the reference's arch file
     for k, fn in steps.items():
         if args.only in (None, k):
             fn(ref, manifest)
