@@ -157,6 +157,15 @@ def test_model_factory_errors(tmp_path, monkeypatch):
         utils.get_model_instance("denoising", "gaussian", "DnCNN", torch.device("cpu"), gray=True)
     with pytest.raises(ValueError, match="No model instance"):
         utils.get_model_instance("deblurring", "motion", "DnCNN", torch.device("cpu"))
+    with pytest.raises(FileNotFoundError):
+        utils.get_model_instance("deblurring", "motion", "DeblurGANv2 (MobileNet)", torch.device("cpu"))
+    with pytest.raises(FileNotFoundError):
+        utils.get_model_instance("denoising", "real", "MaIR", torch.device("cpu"))
+    with pytest.raises(NotImplementedError):      # needs timm's InceptionResNetV2 (not vendored in the reference)
+        open(tmp_path / "x", "w").close()
+        os.makedirs("weights/DeblurGANv2")
+        torch.save({"model": {}}, "weights/DeblurGANv2/fpn_inception.h5")
+        utils.get_model_instance("deblurring", "motion", "DeblurGANv2 (Inception)", torch.device("cpu"))
 
 
 def test_checkpoint_formats_load(tmp_path, monkeypatch, manifest):
@@ -228,6 +237,36 @@ def test_metrics():
     assert p == pytest.approx(tiler_ref.psnr(a, b), abs=1e-12) and 0.9 < s <= 1.0
     assert utils.calculate_metrics(a, a)[0] == float("inf")
     assert utils.calculate_metrics(a, a)[1] == pytest.approx(1.0)
+
+
+def test_harness_aggregate_and_csv(tmp_path):
+    from irm_amd import harness
+    row = harness.aggregate([30.0, 32.0], [0.9, 0.8], [10.0, 14.0], task="deblurring", subtask="motion", dataset="GoPro",
+                            sigma="N/A", model_name="Restormer", params=26126644)
+    assert list(row) == harness.COLUMNS
+    assert row["PSNR"] == 31.0 and row["Std_PSNR"] == 1.0 and row["Avg_Time_ms"] == 12.0 and row["Std_Time_ms"] == 2.0
+    assert row["Task"] == "Deblurring" and row["Type"] == "Motion"
+    path = harness.save_results([row], str(tmp_path))
+    lines = open(path).read().strip().splitlines()
+    assert lines[0] == ",".join(harness.COLUMNS) and lines[1].startswith("Deblurring,Motion,GoPro,N/A,Restormer,26126644,31.0")
+    frames = list(harness.synthetic_loader(2, 24, 32))
+    assert len(frames) == 2 and frames[0][0].shape == (24, 32, 3) and frames[1][2].endswith(".png")
+
+
+def test_new_model_families_parameter_layout(manifest):
+    from irm_amd import deblurganv2
+    m = deblurganv2.FPNMobileNet()
+    assert sorted(m.state_dict().keys()) == manifest["fpn_mobilenet_state_keys"]
+    assert sum(p.numel() for p in m.parameters()) == 3312707
+    with pytest.raises(_hip.HipLibraryError):
+        m(torch.zeros(1, 3, 32, 32))
+    # hooks restate src/deblurganv2/__init__.py:11-28
+    from oracle import deblurgan_ref
+    img = np.arange(60, dtype=np.uint8).reshape(4, 5, 3)
+    assert np.array_equal(deblurganv2.normalize(img), deblurgan_ref.normalize(img))
+    t = torch.zeros(1, 3, 64, 100)
+    assert deblurganv2.pad(t).shape == (1, 3, 96, 128) and torch.equal(deblurganv2.pad(t), deblurgan_ref.pad32(t))
+    assert torch.equal(deblurganv2.postprocess(t), (t + 1) / 2)
 
 
 def test_synth_is_deterministic():
