@@ -90,9 +90,22 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:         # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL prints its version banner on stdout when the communicator is created: keep stdout for the
+        # ONE JSON line by pointing fd 1 at stderr while the communicator comes up
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     model = restormer.Restormer(LayerNorm_type="WithBias").load_synthetic(42).eval().to(dev)
     model.num_streams = args.streams
