@@ -6,6 +6,7 @@ SYNTH_RULES = (
     (r"Ds$", "range", (0.5, 1.5)),
     (r"dt_projs_bias$", "range", (-4.0, -2.0)),
     (r"^output\.weight$", "gain", 0.02),
+    (r"^conv_last\.weight$", "gain", 0.05),
     (r"gating\.gating\.1\.weight$", "gain", 2.0),
 )
 
@@ -16,8 +17,9 @@ import torch as _torch
 import yaml as _yaml
 
 from .mairunet_arch import MaIRUNet  # noqa: E402
+from .mair_arch import MaIR  # noqa: E402
 
-__all__ = ["MaIRUNet", "get_model", "SYNTH_RULES"]
+__all__ = ["MaIRUNet", "MaIR", "get_model", "SYNTH_RULES"]
 
 
 def get_model(opt_path: str):
@@ -28,9 +30,9 @@ def get_model(opt_path: str):
         opt = _yaml.safe_load(f)
     net_opt = dict(opt["network_g"])
     kind = net_opt.pop("type")
-    if kind != "MaIRUNet":
-        raise NotImplementedError(f"network type {kind} is not built in the MI355X path (MaIRUNet is)")
-    model = MaIRUNet(**net_opt)
+    if kind not in ("MaIRUNet", "MaIR"):
+        raise NotImplementedError(f"network type {kind} is not built in the MI355X path")
+    model = MaIRUNet(**net_opt) if kind == "MaIRUNet" else MaIR(**net_opt)
     weights_path = _os.path.expanduser(opt["path"]["pretrain_network_g"])
     ckpt = _torch.load(weights_path, map_location="cpu", weights_only=True)
     sd = ckpt["params"] if "params" in ckpt else ckpt

@@ -29,15 +29,18 @@ from . import SYNTH_RULES
 _IDS_CACHE: dict = {}
 
 
-def _snake(idx: np.ndarray, scan_len: int) -> np.ndarray:
-    """Visit order of the nested S-shaped scan on an index image [H][W]: stripes of `scan_len` columns left to
-    right, odd stripes bottom-up, rows inside a stripe alternately left-to-right / right-to-left."""
+def _snake(idx: np.ndarray, scan_len: int, shift_len: int = 0) -> np.ndarray:
+    """Visit order of the nested S-shaped scan on an index image [H][W]: column stripes left to right (with
+    shift_len > 0 a first stripe of that width, then stripes of `scan_len`), odd stripes bottom-up, rows inside
+    a stripe alternately left-to-right / right-to-left."""
     H, W = idx.shape
-    ns = -(-W // scan_len)
+    edges = [0, shift_len] if shift_len else [0]
+    while edges[-1] < W:
+        edges.append(min(edges[-1] + scan_len, W))
     order = []
     hv = np.arange(H)
-    for s in range(ns):
-        cols = np.arange(s * scan_len, min((s + 1) * scan_len, W))
+    for s in range(len(edges) - 1):
+        cols = np.arange(edges[s], edges[s + 1])
         rows = (H - 1 - hv) if s % 2 else hv
         block = idx[rows][:, cols]                    # [H][w] in visit order of the rows
         block[1::2] = block[1::2, ::-1]               # odd visited rows run right to left
@@ -45,13 +48,14 @@ def _snake(idx: np.ndarray, scan_len: int) -> np.ndarray:
     return np.concatenate(order)
 
 
-def scan_ids(H: int, W: int, scan_len: int, device) -> torch.Tensor:
-    """[4][H*W] int32 on `device`: direction 0 the image, 1 rotated by 180 degrees, 2 transposed, 3 both."""
-    key = (H, W, scan_len, str(device))
+def scan_ids(H: int, W: int, scan_len: int, device, shift_len: int = 0) -> torch.Tensor:
+    """[4][H*W] int32 on `device`: direction 0 the image, 1 rotated by 180 degrees, 2 transposed, 3 both
+    (mair_ids_generate / mair_shift_ids_generate, shift_scanf_util.py:169-203)."""
+    key = (H, W, scan_len, shift_len, str(device))
     if key not in _IDS_CACHE:
         idx = np.arange(H * W).reshape(H, W)
         rot = idx[::-1, ::-1]
-        ids = np.stack([_snake(idx, scan_len), _snake(rot, scan_len), _snake(idx.T, scan_len), _snake(rot.T, scan_len)])
+        ids = np.stack([_snake(m, scan_len, shift_len) for m in (idx, rot, idx.T, rot.T)])
         _IDS_CACHE[key] = torch.from_numpy(ids.astype(np.int32)).to(device)
     return _IDS_CACHE[key]
 
@@ -88,15 +92,21 @@ class Mlp(nn.Module):
 
 
 class VSSBlock(nn.Module):
-    def __init__(self, hidden_dim, d_state, ssm_ratio, mlp_ratio, bias=False):
+    """mairunet_arch.py:332-380; `mlp_name='conv_blk'` gives the flat MaIR's RMB (mair_arch.py:346-390)."""
+
+    def __init__(self, hidden_dim, d_state, ssm_ratio, mlp_ratio, bias=False, mlp_name="mlp"):
         super().__init__()
-        self.hidden_dim = hidden_dim
+        self.hidden_dim, self.mlp_name = hidden_dim, mlp_name
         self.ln_1 = nn.LayerNorm(hidden_dim)
         self.self_attention = LoSh2D(hidden_dim, d_state, ssm_ratio, bias=bias)
         self.skip_scale = nn.Parameter(torch.ones(hidden_dim))
-        self.mlp = Mlp(hidden_dim, int(hidden_dim * mlp_ratio))
+        setattr(self, mlp_name, Mlp(hidden_dim, int(hidden_dim * mlp_ratio)))
         self.ln_2 = nn.LayerNorm(hidden_dim)
         self.skip_scale2 = nn.Parameter(torch.ones(hidden_dim))
+
+    @property
+    def ffn(self):
+        return getattr(self, self.mlp_name)
 
 
 class _Proj(nn.Module):
@@ -111,90 +121,40 @@ class _Resample(nn.Module):
         self.body = nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1, bias=False))
 
 
-class MaIRUNet(nn.Module):
-    def __init__(self, inp_channels=3, out_channels=3, dim=48, num_blocks=(4, 6, 6, 8), ssm_ratio=1.5,
-                 num_refinement_blocks=4, drop_path_rate=0., bias=False, dual_pixel_task=False, flp_ratio=2,
-                 mlp_ratio=2, dynamic_ids=False, img_size=64, scan_len=8, batch_size=1):
-        super().__init__()
-        self.inp_channels, self.out_channels, self.dim, self.scan_len = inp_channels, out_channels, dim, scan_len
-        d1, d2, d3, d4 = dim, dim * 2, dim * 4, dim * 8
+def pack_block(m: VSSBlock) -> dict:
+    """Packed / flattened device copies of one block's weights."""
+    def f32(t):
+        return None if t is None else t.detach().float().contiguous()
+    a = m.self_attention
+    D = a.d_inner
+    return dict(
+        inp=_hip.pack_gemm_weight(a.in_proj.weight), inp_b=f32(a.in_proj.bias),
+        dw=f32(a.conv2d.weight.reshape(D, 9)), dw_b=f32(a.conv2d.bias),
+        xproj=_hip.pack_gemm_weight(a.x_proj_weight.reshape(-1, D)),
+        dtw=f32(a.dt_projs_weight), dtb=f32(a.dt_projs_bias),
+        A=f32(-torch.exp(a.A_logs.detach().float())), Ds=f32(a.Ds),
+        gw=f32(a.gating.gating[1].weight.reshape(4 * D, 4)), gb=f32(a.gating.gating[1].bias),
+        onw=f32(a.out_norm.weight), onb=f32(a.out_norm.bias),
+        outp=_hip.pack_gemm_weight(a.out_proj.weight), outp_b=f32(a.out_proj.bias),
+        ln1w=f32(m.ln_1.weight), ln1b=f32(m.ln_1.bias), ln2w=f32(m.ln_2.weight), ln2b=f32(m.ln_2.bias),
+        s1=f32(m.skip_scale), s2=f32(m.skip_scale2),
+        fc1=_hip.pack_gemm_weight(m.ffn.fc1.weight), fc1_b=f32(m.ffn.fc1.bias),
+        fc2=_hip.pack_gemm_weight(m.ffn.fc2.weight), fc2_b=f32(m.ffn.fc2.bias))
 
-        def stage(c, n, d_state, ratio):
-            return nn.ModuleList([VSSBlock(c, d_state, ssm_ratio, ratio, bias=False) for _ in range(n)])
 
-        self.patch_embed = _Proj(inp_channels, d1)
-        self.encoder_level1 = stage(d1, num_blocks[0], 4, flp_ratio)
-        self.down1_2 = _Resample(d1, d1 // 2)
-        self.encoder_level2 = stage(d2, num_blocks[1], 8, mlp_ratio)
-        self.down2_3 = _Resample(d2, d2 // 2)
-        self.encoder_level3 = stage(d3, num_blocks[2], 16, mlp_ratio)
-        self.down3_4 = _Resample(d3, d3 // 2)
-        self.latent = stage(d4, num_blocks[3], 32, mlp_ratio)
-        self.up4_3 = _Resample(d4, d4 * 2)
-        self.reduce_chan_level3 = nn.Conv2d(d4, d3, 1, bias=bias)
-        self.decoder_level3 = stage(d3, num_blocks[2], 16, mlp_ratio)
-        self.up3_2 = _Resample(d3, d3 * 2)
-        self.reduce_chan_level2 = nn.Conv2d(d3, d2, 1, bias=bias)
-        self.decoder_level2 = stage(d2, num_blocks[1], 8, mlp_ratio)
-        self.up2_1 = _Resample(d2, d2 * 2)
-        self.decoder_level1 = stage(d2, num_blocks[0], 8, mlp_ratio)
-        self.refinement = stage(d2, num_refinement_blocks, 8, mlp_ratio)
-        self.dual_pixel_task = dual_pixel_task
-        if dual_pixel_task:
-            self.skip_conv = nn.Conv2d(d1, d2, 1, bias=bias)
-        self.output = nn.Conv2d(d2, out_channels, 3, padding=1, bias=bias)
+class MambaHost(nn.Module):
+    """Workspace + the VSSBlock driver shared by MaIRUNet and the flat MaIR."""
+
+    def _init_host(self):
         self._packed, self._packed_key, self._ws_by_stream = None, None, {}
-        self.max_tiles_per_batch = 4
 
-    # ------------------------------------------------------------------ weights
-    def load_synthetic(self, seed=42):
-        from .. import synth
-        shapes = {k: tuple(v.shape) for k, v in self.state_dict().items()}
-        self.load_state_dict(synth.synth_state_dict(shapes, seed=seed, rules=SYNTH_RULES), strict=True)
-        return self
-
-    def _pack(self):
+    def _param_key(self):
         ver, dev = 0, None
         for p in self.parameters():
             dev = p.device
             ver += p._version + (p.data_ptr() & 0xFFFF)
-        key = (str(dev), ver)
-        if self._packed is not None and self._packed_key == key:
-            return self._packed
+        return (str(dev), ver)
 
-        def f32(t):
-            return None if t is None else t.detach().float().contiguous()
-
-        pk = {}
-        for name, m in self.named_modules():
-            if isinstance(m, VSSBlock):
-                a = m.self_attention
-                D = a.d_inner
-                pk[name] = dict(
-                    inp=_hip.pack_gemm_weight(a.in_proj.weight), inp_b=f32(a.in_proj.bias),
-                    dw=f32(a.conv2d.weight.reshape(D, 9)), dw_b=f32(a.conv2d.bias),
-                    xproj=_hip.pack_gemm_weight(a.x_proj_weight.reshape(-1, D)),
-                    dtw=f32(a.dt_projs_weight), dtb=f32(a.dt_projs_bias),
-                    A=f32(-torch.exp(a.A_logs.detach().float())), Ds=f32(a.Ds),
-                    gw=f32(a.gating.gating[1].weight.reshape(4 * D, 4)), gb=f32(a.gating.gating[1].bias),
-                    onw=f32(a.out_norm.weight), onb=f32(a.out_norm.bias),
-                    outp=_hip.pack_gemm_weight(a.out_proj.weight), outp_b=f32(a.out_proj.bias),
-                    ln1w=f32(m.ln_1.weight), ln1b=f32(m.ln_1.bias), ln2w=f32(m.ln_2.weight), ln2b=f32(m.ln_2.bias),
-                    s1=f32(m.skip_scale), s2=f32(m.skip_scale2),
-                    fc1=_hip.pack_gemm_weight(m.mlp.fc1.weight), fc1_b=f32(m.mlp.fc1.bias),
-                    fc2=_hip.pack_gemm_weight(m.mlp.fc2.weight), fc2_b=f32(m.mlp.fc2.bias))
-        for name in ("down1_2", "down2_3", "down3_4", "up4_3", "up3_2", "up2_1"):
-            pk[name] = _hip.pack_conv3x3_weight(getattr(self, name).body[0].weight)
-        pk["patch_embed"] = _hip.pack_conv3x3_weight(self.patch_embed.proj.weight)
-        pk["output"] = _hip.pack_conv3x3_weight(self.output.weight)
-        pk["output_b"] = f32(self.output.bias)
-        for name in ("reduce_chan_level3", "reduce_chan_level2") + (("skip_conv",) if self.dual_pixel_task else ()):
-            pk[name] = _hip.pack_gemm_weight(getattr(self, name).weight)
-            pk[name + "_b"] = f32(getattr(self, name).bias)
-        self._packed, self._packed_key = pk, key
-        return pk
-
-    # ------------------------------------------------------------------ workspace
     def _buf(self, name, numel, device):
         ws = self._ws_by_stream.setdefault(torch.cuda.current_stream().cuda_stream, {})
         t = ws.get(name)
@@ -214,7 +174,7 @@ class MaIRUNet(nn.Module):
         a = blk.self_attention
         D, N, R = a.d_inner, a.d_state, a.dt_rank
         J = R + 2 * N
-        hid = blk.mlp.fc1.out_features
+        hid = blk.ffn.fc1.out_features
         fuse = ops.can_fuse_stats(C)
         stats = self._buf("stats", B * 2 * L, dev)
         xz = self._buf("xz", B * 2 * D * L, dev).view(B, 2 * D, H, W)
@@ -252,6 +212,70 @@ class MaIRUNet(nn.Module):
         ops.gemm1x1(w["fc2"], h, x, C, hid, res=x, bias=w["fc2_b"], res_scale=w["s2"],
                     stats_out=stats if emit else None)
         return emit
+
+
+
+class MaIRUNet(MambaHost):
+    def __init__(self, inp_channels=3, out_channels=3, dim=48, num_blocks=(4, 6, 6, 8), ssm_ratio=1.5,
+                 num_refinement_blocks=4, drop_path_rate=0., bias=False, dual_pixel_task=False, flp_ratio=2,
+                 mlp_ratio=2, dynamic_ids=False, img_size=64, scan_len=8, batch_size=1):
+        super().__init__()
+        self.inp_channels, self.out_channels, self.dim, self.scan_len = inp_channels, out_channels, dim, scan_len
+        d1, d2, d3, d4 = dim, dim * 2, dim * 4, dim * 8
+
+        def stage(c, n, d_state, ratio):
+            return nn.ModuleList([VSSBlock(c, d_state, ssm_ratio, ratio, bias=False) for _ in range(n)])
+
+        self.patch_embed = _Proj(inp_channels, d1)
+        self.encoder_level1 = stage(d1, num_blocks[0], 4, flp_ratio)
+        self.down1_2 = _Resample(d1, d1 // 2)
+        self.encoder_level2 = stage(d2, num_blocks[1], 8, mlp_ratio)
+        self.down2_3 = _Resample(d2, d2 // 2)
+        self.encoder_level3 = stage(d3, num_blocks[2], 16, mlp_ratio)
+        self.down3_4 = _Resample(d3, d3 // 2)
+        self.latent = stage(d4, num_blocks[3], 32, mlp_ratio)
+        self.up4_3 = _Resample(d4, d4 * 2)
+        self.reduce_chan_level3 = nn.Conv2d(d4, d3, 1, bias=bias)
+        self.decoder_level3 = stage(d3, num_blocks[2], 16, mlp_ratio)
+        self.up3_2 = _Resample(d3, d3 * 2)
+        self.reduce_chan_level2 = nn.Conv2d(d3, d2, 1, bias=bias)
+        self.decoder_level2 = stage(d2, num_blocks[1], 8, mlp_ratio)
+        self.up2_1 = _Resample(d2, d2 * 2)
+        self.decoder_level1 = stage(d2, num_blocks[0], 8, mlp_ratio)
+        self.refinement = stage(d2, num_refinement_blocks, 8, mlp_ratio)
+        self.dual_pixel_task = dual_pixel_task
+        if dual_pixel_task:
+            self.skip_conv = nn.Conv2d(d1, d2, 1, bias=bias)
+        self.output = nn.Conv2d(d2, out_channels, 3, padding=1, bias=bias)
+        self._init_host()
+        self.max_tiles_per_batch = 4
+
+    # ------------------------------------------------------------------ weights
+    def load_synthetic(self, seed=42):
+        from .. import synth
+        shapes = {k: tuple(v.shape) for k, v in self.state_dict().items()}
+        self.load_state_dict(synth.synth_state_dict(shapes, seed=seed, rules=SYNTH_RULES), strict=True)
+        return self
+
+    def _pack(self):
+        key = self._param_key()
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+
+        def f32(t):
+            return None if t is None else t.detach().float().contiguous()
+
+        pk = {name: pack_block(m) for name, m in self.named_modules() if isinstance(m, VSSBlock)}
+        for name in ("down1_2", "down2_3", "down3_4", "up4_3", "up3_2", "up2_1"):
+            pk[name] = _hip.pack_conv3x3_weight(getattr(self, name).body[0].weight)
+        pk["patch_embed"] = _hip.pack_conv3x3_weight(self.patch_embed.proj.weight)
+        pk["output"] = _hip.pack_conv3x3_weight(self.output.weight)
+        pk["output_b"] = f32(self.output.bias)
+        for name in ("reduce_chan_level3", "reduce_chan_level2") + (("skip_conv",) if self.dual_pixel_task else ()):
+            pk[name] = _hip.pack_gemm_weight(getattr(self, name).weight)
+            pk[name + "_b"] = f32(getattr(self, name).bias)
+        self._packed, self._packed_key = pk, key
+        return pk
 
     def _run_stage(self, name, pk, x, ids):
         blocks = getattr(self, name)

@@ -23,13 +23,13 @@ from .configs import PATCH_CONFIG, ROOT_RESULTS_DIR, ROOT_WEIGHTS_DIR
 from .dncnn import DnCNN
 from .rednet import REDNet
 from .restormer import Restormer
-from .mair import MaIRUNet
+from .mair import MaIR, MaIRUNet
 from .deblurganv2 import FPNMobileNet
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 
 #: model classes whose forward is the HIP path (isinstance dispatch as in utils.py:280/292)
-_PAD8_MODELS = (Restormer, MaIRUNet)
+_PAD8_MODELS = (Restormer, MaIR, MaIRUNet)
 
 
 def get_model_total_parameters(model: Module) -> int:
@@ -127,8 +127,7 @@ def get_model_instance(task, subtask, model_name, device: torch.device, gray=Fal
         opt_dir = os.path.join(_PKG_DIR, 'mair', 'options')
         if task == 'denoising':
             if subtask == 'gaussian' and not gray and sigma is not None:
-                raise NotImplementedError('MaIR (flat, mair_arch.py) for colour Gaussian denoising is not built yet '
-                                          'in the MI355X path; MaIRUNet (real denoising / motion deblurring) is')
+                return mair.get_model(os.path.join(opt_dir, f'test_MaIR_CDN_s{sigma}.yml'))
             if subtask == 'real':
                 return mair.get_model(os.path.join(opt_dir, 'test_MaIR_RealDN.yml'))
         if task == 'deblurring' and subtask == 'motion':

@@ -332,11 +332,15 @@ def import_reference_mairunet():
     pkg("mair.basicsr", base + "/basicsr")
     pkg("mair.basicsr.utils", base + "/basicsr/utils")
     pkg("mair.basicsr.utils.registry", ARCH_REGISTRY=_Reg())
+    pkg("mair.basicsr.archs", base + "/basicsr/archs")
     pkg("mair.realDenoising", base + "/realDenoising")
     pkg("mair.realDenoising.basicsr", base + "/realDenoising/basicsr")
     pkg("mair.realDenoising.basicsr.models", base + "/realDenoising/basicsr/models")
     pkg("mair.realDenoising.basicsr.models.archs", base + "/realDenoising/basicsr/models/archs")
-    return importlib.import_module("mair.realDenoising.basicsr.models.archs.mairunet_arch")
+    flat = importlib.import_module("mair.basicsr.archs.mair_arch")
+    unet = importlib.import_module("mair.realDenoising.basicsr.models.archs.mairunet_arch")
+    unet.flat = flat
+    return unet
 
 
 def gen_mair(ref, manifest):
@@ -382,6 +386,30 @@ def gen_mair(ref, manifest):
         print(f"vssblock c{c}: oracle-vs-reference {d:.3e}")
         assert d <= 2e-5
         out[f"vss_c{c}_{h}x{w}"] = y.numpy()
+    # ---- flat MaIR (colour Gaussian denoising, options/test_MaIR_CDN_s*.yml) incl. the shifted scan tables
+    for (h, w, sl) in [(4, 8, 4), (16, 16, 4), (6, 10, 4), (5, 7, 4), (12, 9, 4)]:
+        a, ai = ssu.mair_shift_ids_generate((1, 1, h, w), scan_len=sl, shift_len=sl // 2)
+        b, bi = mair_ref.scan_ids(h, w, sl, sl // 2)
+        assert torch.equal(a.reshape(4, -1), b) and torch.equal(ai.reshape(4, -1), bi), (h, w)
+        out[f"shift_ids_{h}x{w}_s{sl}"] = a.reshape(4, -1).numpy().astype(np.int32)
+    flat_cfg = dict(upscale=1, in_chans=3, img_range=1., d_state=16, depths=[2, 2], embed_dim=180, ssm_ratio=1.3,
+                    mlp_ratio=2.0, upsampler=None, resi_connection='1conv', img_size=16, dynamic_ids=False,
+                    batch_size=1, scan_len=4)       # test_MaIR_CDN_s25.yml network_g with fewer groups/blocks
+    fnet = arch.flat.MaIR(**flat_cfg)
+    fshapes = shapes_of(fnet)
+    manifest["mair_flat_param_shapes_depths2x2"] = {k: list(v) for k, v in fshapes.items()}
+    fsd = synth.synth_state_dict(fshapes, seed=42, rules=MAIR_RULES)
+    fnet.load_state_dict(fsd, strict=True)
+    fnet.train()
+    for (h, w) in [(16, 16), (24, 20)]:
+        x = synth_input(f"mairflat_in_{h}x{w}", (1, 3, h, w))
+        y_ref = fnet(x)
+        y_orc = mair_ref.mair_forward(x, fsd, scan_len=4)
+        d = maxabs(y_ref, y_orc)
+        manifest["oracle_vs_reference"][f"mair_flat/{h}x{w}(scan op = oracle stand-in)"] = d
+        print(f"mair flat {h}x{w}: oracle-vs-reference {d:.3e} |y-x| mean {float((y_ref - x).abs().mean()):.4f}")
+        assert d <= 2e-5
+        out[f"mairflat_{h}x{w}"] = y_ref.detach().numpy()
     np.savez_compressed(os.path.join(GOLD, "mair.npz"), **out)
 
 

@@ -2,7 +2,7 @@
 
 CPU restatement (functional PyTorch fp32) of MaIRUNet's forward
 (src/mair/realDenoising/basicsr/models/archs/mairunet_arch.py:21-739), its scan-index tables
-(shift_scanf_util.py:67-244, unshifted variant - MaIRUNet never passes shift_size, :476-581) and of the
+(shift_scanf_util.py:67-244; MaIRUNet never passes shift_size, :476-581, the flat MaIR alternates) and of the
 third-party selective scan it calls (mamba_ssm==2.2.5 `selective_scan_fn`, NOT in the reference tree).
 
 Pinning: everything except `selective_scan` is checked against the imported reference module by
@@ -20,26 +20,30 @@ import torch.nn.functional as F
 
 
 # --------------------------------------------------------------------------- scan index tables
-def _snake(idx: np.ndarray, scan_len: int) -> np.ndarray:
-    """Visit order of `sscan` (shift_scanf_util.py:67-126, shift_len=0) on an index image [H][W]:
-    column stripes of width scan_len left to right; odd stripes bottom-up; inside a stripe a
-    boustrophedon over rows (odd visited rows right-to-left)."""
+def _snake(idx: np.ndarray, scan_len: int, shift_len: int = 0) -> np.ndarray:
+    """Visit order of `sscan` (shift_scanf_util.py:67-126) on an index image [H][W]: column stripes left to
+    right - with shift_len > 0 a first stripe of width shift_len, then stripes of scan_len -, every odd
+    stripe bottom-up; inside a stripe a boustrophedon over rows (odd visited rows right-to-left)."""
     H, W = idx.shape
+    edges = ([0, shift_len] if shift_len else [0])
+    while edges[-1] < W:
+        edges.append(min(edges[-1] + scan_len, W))
     out = []
-    for s in range(-(-W // scan_len)):
-        cols = np.arange(s * scan_len, min((s + 1) * scan_len, W))
+    for s in range(len(edges) - 1):
+        cols = np.arange(edges[s], edges[s + 1])
         for hv in range(H):
             row = H - 1 - hv if s % 2 else hv
             out.append(idx[row, cols[::-1] if hv % 2 else cols])
     return np.concatenate(out)
 
 
-def scan_ids(H: int, W: int, scan_len: int = 4):
-    """(ids [4][L], inverse [4][L]) int64 as mair_ids_generate (shift_scanf_util.py:169-179) returns them:
-    direction 0 the image, 1 the image rotated by 180 degrees, 2 its transpose, 3 the rotated transpose."""
+def scan_ids(H: int, W: int, scan_len: int = 4, shift_len: int = 0):
+    """(ids [4][L], inverse [4][L]) int64 as mair_ids_generate / mair_shift_ids_generate
+    (shift_scanf_util.py:169-203) return them: direction 0 the image, 1 the image rotated by 180 degrees,
+    2 its transpose, 3 the rotated transpose."""
     idx = np.arange(H * W).reshape(H, W)
     rot = idx[::-1, ::-1]
-    ids = np.stack([_snake(idx, scan_len), _snake(rot, scan_len), _snake(idx.T, scan_len), _snake(rot.T, scan_len)])
+    ids = np.stack([_snake(m, scan_len, shift_len) for m in (idx, rot, idx.T, rot.T)])
     return torch.from_numpy(ids.copy()), torch.from_numpy(np.argsort(ids, axis=-1))
 
 
@@ -106,15 +110,16 @@ def losh2d(x, p, pre, ids, inv):
     return F.linear(y, p[pre + "out_proj.weight"], p.get(pre + "out_proj.bias"))
 
 
-def vss_block(x, p, pre, hw, ids, inv):
-    """VSSBlock.forward (mairunet_arch.py:362-380) on tokens x (B, L, C)."""
+def vss_block(x, p, pre, hw, ids, inv, mlp="mlp"):
+    """VSSBlock.forward (mairunet_arch.py:362-380) / RMB.forward (mair_arch.py:376-390, MLP named conv_blk)
+    on tokens x (B, L, C)."""
     B, L, C = x.shape
     xi = x.view(B, hw[0], hw[1], C)
     h = F.layer_norm(xi, (C,), p[pre + "ln_1.weight"], p[pre + "ln_1.bias"], 1e-5)
     xi = xi * p[pre + "skip_scale"] + losh2d(h, p, pre + "self_attention.", ids, inv)
     h = F.layer_norm(xi, (C,), p[pre + "ln_2.weight"], p[pre + "ln_2.bias"], 1e-5)
-    h = F.linear(F.gelu(F.linear(h, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"])),
-                 p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
+    h = F.linear(F.gelu(F.linear(h, p[pre + mlp + ".fc1.weight"], p[pre + mlp + ".fc1.bias"])),
+                 p[pre + mlp + ".fc2.weight"], p[pre + mlp + ".fc2.bias"])
     return (xi * p[pre + "skip_scale2"] + h).view(B, L, C)
 
 
@@ -161,3 +166,33 @@ def mairunet_forward(x, p, scan_len=4, dual_pixel_task=False):
         d1 = d1 + F.conv2d(_img(e1_in, sizes[0]), p["skip_conv.weight"], p.get("skip_conv.bias"))
         return F.conv2d(d1, p["output.weight"], p.get("output.bias"), padding=1)
     return F.conv2d(d1, p["output.weight"], p.get("output.bias"), padding=1) + x
+
+
+RGB_MEAN = (0.4488, 0.4371, 0.4040)
+
+
+def mair_forward(x, p, scan_len=4, img_range=1.0):
+    """MaIR.forward, denoising branch (upsampler=None) (src/mair/basicsr/archs/mair_arch.py:682-730):
+    mean shift, conv_first, patch-norm, residual Mamba groups (blocks alternate the unshifted / shifted
+    scan tables, mair_arch.py:455, 379-382; each group ends in conv3x3 + residual, :863-864), final norm,
+    conv_after_body + residual, conv_last + input residual, un-shift."""
+    B, C, H, W = x.shape
+    hw = (H, W)
+    mean = (torch.tensor(RGB_MEAN) if C == 3 else torch.zeros(1)).view(1, -1, 1, 1).to(x)
+    tabs = [scan_ids(H, W, scan_len), scan_ids(H, W, scan_len, scan_len // 2)]
+    x = (x - mean) * img_range
+    first = F.conv2d(x, p["conv_first.weight"], p["conv_first.bias"], padding=1)
+    E = first.shape[1]
+    t = F.layer_norm(_tok(first), (E,), p["patch_embed.norm.weight"], p["patch_embed.norm.bias"], 1e-5)
+    li = 0
+    while f"layers.{li}.conv.weight" in p:
+        g_in, bi = t, 0
+        while f"layers.{li}.residual_group.blocks.{bi}.ln_1.weight" in p:
+            t = vss_block(t, p, f"layers.{li}.residual_group.blocks.{bi}.", hw, *tabs[bi % 2], mlp="conv_blk")
+            bi += 1
+        t = _tok(F.conv2d(_img(t, hw), p[f"layers.{li}.conv.weight"], p[f"layers.{li}.conv.bias"], padding=1)) + g_in
+        li += 1
+    t = F.layer_norm(t, (E,), p["norm.weight"], p["norm.bias"], 1e-5)
+    res = F.conv2d(_img(t, hw), p["conv_after_body.weight"], p["conv_after_body.bias"], padding=1) + first
+    x = x + F.conv2d(res, p["conv_last.weight"], p["conv_last.bias"], padding=1)
+    return x / img_range + mean

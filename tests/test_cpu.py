@@ -98,6 +98,11 @@ def test_mair_oracle_and_ids_vs_golden(golden, manifest):
             assert np.array_equal(mair_ref.scan_ids(h, w, sl)[0].numpy(), golden("mair")[key])
     from irm_amd.mair import mairunet_arch
     assert np.array_equal(mairunet_arch.scan_ids(6, 10, 4, "cpu").numpy(), golden("mair")["ids_6x10_s4"])
+    for key in golden("mair").files:
+        if key.startswith("shift_ids_"):
+            h, w = map(int, key.split("_")[2].split("x"))
+            assert np.array_equal(mair_ref.scan_ids(h, w, 4, 2)[0].numpy(), golden("mair")[key])
+            assert np.array_equal(mairunet_arch.scan_ids(h, w, 4, "cpu", 2).numpy(), golden("mair")[key])
     shapes = {k: tuple(v) for k, v in manifest["mairunet_param_shapes"].items()}
     from irm_amd import mair
     assert {k: list(v.shape) for k, v in mair.MaIRUNet(

@@ -136,3 +136,26 @@ def test_mairunet_batch_and_determinism(dev):
     y1, y2 = model(x).clone(), model(x).clone()
     assert torch.equal(y1, y2)
     assert (model(x[1:2]) - y1[1:2]).abs().max() <= 5e-5
+
+
+FLAT_CFG = dict(upscale=1, in_chans=3, img_range=1., d_state=16, depths=[2, 2], embed_dim=180, ssm_ratio=1.3, mlp_ratio=2.0,
+                upsampler=None, resi_connection='1conv', img_size=16, dynamic_ids=False, batch_size=1, scan_len=4)
+
+
+@pytest.mark.parametrize("h,w", [(16, 16), (24, 20)])
+def test_mair_flat_vs_golden(dev, golden, h, w):
+    """Flat MaIR (shifted scan tables on odd blocks, C=180 / D=234 not multiples of 16 or 64) vs reference goldens."""
+    model = mair.MaIR(**FLAT_CFG).load_synthetic(42).eval().to(dev)
+    x = gin(f"mairflat_in_{h}x{w}", (1, 3, h, w))
+    y = model(x.to(dev)).cpu().numpy()
+    err = np.abs(y - golden("mair")[f"mairflat_{h}x{w}"]).max()
+    print(f"mair flat {h}x{w}: max-abs vs reference golden {err:.3e}")
+    assert err <= 1e-3
+
+
+def test_shifted_scan_tables_vs_golden(golden):
+    for key in golden("mair").files:
+        if key.startswith("shift_ids_"):
+            h, w = map(int, key.split("_")[2].split("x"))
+            sl = int(key.split("_s")[-1])
+            assert np.array_equal(arch.scan_ids(h, w, sl, "cpu", sl // 2).numpy(), golden("mair")[key])
