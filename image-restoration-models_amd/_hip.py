@@ -26,6 +26,7 @@ SIGNATURES = {
     "irm_gemm1x1_f32": [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P],
     "irm_dwconv3x3_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
     "irm_dwconv3x3_gate_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "irm_dwgemm_f32": [_P, _L, _P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _F, _P],
     "irm_mdta_gram_f32": [_P, _L, _P, _I, _I, _I, _I, _I, _P],
     "irm_mdta_finalize_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "irm_conv3x3_f32": [_P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -109,6 +110,23 @@ def pack_conv3x3_weight(w: torch.Tensor) -> torch.Tensor:
     wpad = torch.zeros(9, mt * 16, ks * 4, dtype=torch.float32, device=w.device)
     wpad[:, :co, :ci] = w.reshape(co, ci, 9).permute(2, 0, 1)
     return wpad.view(9, mt, 16, ks, 4).permute(0, 1, 3, 4, 2).contiguous().view(-1)
+
+
+def pack_dw_table(w9: torch.Tensor, bias, K: int, gate: bool) -> torch.Tensor:
+    """Depth-wise coefficients in irm_dwgemm_f32's per-stage order: w9 [K or 2K][9] (+ bias) ->
+    [4*ceil(K/4)][40 | 20] floats, every value twice (include/irm_hip.h)."""
+    w9 = w9.detach().reshape(-1, 9).float()
+    n = 20 if gate else 10
+    rows = 4 * ((K + 3) // 4)
+    t = torch.zeros(rows, n, dtype=torch.float32, device=w9.device)
+    t[:K, 0:9] = w9[:K]
+    if bias is not None:
+        t[:K, 9] = bias[:K].float()
+    if gate:
+        t[:K, 10:19] = w9[K:2 * K]
+        if bias is not None:
+            t[:K, 19] = bias[K:2 * K].float()
+    return t.repeat_interleave(2, dim=1).contiguous().view(-1)
 
 
 def deconv_as_conv_weight(w: torch.Tensor) -> torch.Tensor:

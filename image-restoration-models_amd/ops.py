@@ -130,6 +130,29 @@ def dwconv3x3_gate(x, w9, y, *, bias=None):
             tag=f"hid{C2 // 2} {H}x{W} B{B}")
 
 
+def can_fuse_dw(M: int, W: int) -> bool:
+    """irm_dwgemm_f32 keeps every output channel of a pixel tile in one workgroup."""
+    return M <= 96 and W % 4 == 0
+
+
+def dwgemm(wp, dwp, x, y, M: int, K: int, *, gate: bool, res=None, bias=None, w_bs: int = 0, stats_out=None,
+           eps: float = 1e-5):
+    """y = W @ g + bias (+ res), g = gelu(dw(x[:, :K])) * dw(x[:, K:2K]) (gate) or dw(x[:, :K]);
+    dwp from _hip.pack_dw_table."""
+    _chk(x, "x"), _chk(y, "y")
+    B, Cx, H, W = x.shape
+    assert Cx >= (2 * K if gate else K) and y.shape[1] >= M
+    if res is not None:
+        _chk(res, "res")
+    N = H * W
+    nbytes = 4.0 * B * N * ((2 * K if gate else K) + M + (M if res is not None else 0)
+                            + (2 if stats_out is not None else 0))
+    flops = B * N * (2.0 * M * K + (36.0 if gate else 18.0) * K)
+    _launch("dwgemm", flops, nbytes, "irm_dwgemm_f32", _hip.ptr(wp), int(w_bs), _hip.ptr(dwp), _hip.ptr(x), _bs(x),
+            _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), int(bool(gate)), B, M, K, H, W,
+            _hip.ptr(stats_out), float(eps), tag=f"M{M} K{K} {H}x{W} B{B} gate{int(bool(gate))}")
+
+
 def mdta_plan(B: int, C: int, heads: int, N: int):
     """(chunk, nchunk, record size) of the Gram pass for this problem size."""
     c = C // heads

@@ -21,6 +21,8 @@ There is no PyTorch fallback: without the HIP library ``forward`` raises.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -178,6 +180,12 @@ class Restormer(nn.Module):
                     ffn_dw=f32(ff.dwconv.weight.reshape(-1, 9)), ffn_dw_b=f32(ff.dwconv.bias),
                     pout=_hip.pack_gemm_weight(ff.project_out.weight), pout_b=f32(ff.project_out.bias),
                     n1w=f32(m.norm1.w), n1b=f32(m.norm1.b), n2w=f32(m.norm2.w), n2b=f32(m.norm2.b))
+                if ops.can_fuse_dw(m.dim, 4):
+                    # depth-wise coefficient tables of the fused dw + 1x1 kernel (irm_dwgemm_f32)
+                    c, dw, dwb = m.dim, a.qkv_dwconv.weight.reshape(-1, 9), a.qkv_dwconv.bias
+                    pk[name].update(
+                        v_dwp=_hip.pack_dw_table(dw[2 * c:], None if dwb is None else dwb[2 * c:], c, False),
+                        ffn_dwp=_hip.pack_dw_table(ff.dwconv.weight, ff.dwconv.bias, ff.hidden, True))
         for name in ("down1_2", "down2_3", "down3_4", "up4_3", "up3_2", "up2_1"):
             pk[name] = _hip.pack_conv3x3_weight(getattr(self, name).body[0].weight)
         pk["patch_embed"] = _hip.pack_conv3x3_weight(self.patch_embed.proj.weight)
@@ -232,7 +240,13 @@ class Restormer(nn.Module):
             ops.ln_stats(x, stats)
         ops.gemm1x1(w["qkv"], x, qkv, 3 * C, C, bias=w["qkv_b"], stats=stats, lnw=w["n1w"], lnb=w["n1b"],
                     ln_mode=blk.norm1.mode)
-        ops.dwconv3x3(qkv, w["qkv_dw"], qkv2, bias=w["qkv_dw_b"])
+        fuse_dw = "v_dwp" in w and ops.can_fuse_dw(C, W) and not os.environ.get("IRM_NO_FUSE_DW")
+        if fuse_dw:
+            # q, k only: the depth-wise conv of v happens inside the apply GEMM below
+            ops.dwconv3x3(qkv[:, :2 * C], w["qkv_dw"], qkv2[:, :2 * C],
+                          bias=None if w["qkv_dw_b"] is None else w["qkv_dw_b"][:2 * C])
+        else:
+            ops.dwconv3x3(qkv, w["qkv_dw"], qkv2, bias=w["qkv_dw_b"])
         _, nchunk, rec = ops.mdta_plan(B, C, heads, N)
         part = self._buf("gram_part", B * heads * nchunk * rec, dev)
         gsum = self._buf("gram_sum", B * heads * rec, dev)
@@ -243,8 +257,12 @@ class Restormer(nn.Module):
             mfold = torch.zeros(B * mfold_n, dtype=torch.float32, device=dev)
             ws[("mfold", C, B)] = mfold
         ops.mdta_fold(qkv2, part, gsum, w["temp"], w["wout"], mfold, C, heads)
-        ops.gemm1x1(mfold, qkv2[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n,
-                    stats_out=stats if fuse else None)
+        if fuse_dw:
+            ops.dwgemm(mfold, w["v_dwp"], qkv[:, 2 * C:], x, C, C, gate=False, res=x, bias=w["wout_b"],
+                       w_bs=mfold_n, stats_out=stats if fuse else None)
+        else:
+            ops.gemm1x1(mfold, qkv2[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n,
+                        stats_out=stats if fuse else None)
         # --- feed-forward branch: x += project_out(gelu(dw(h1)) * dw(h2))   (restormer.py:88-93, 148)
         h = big_a[:B * 2 * hid * N].view(B, 2 * hid, H, W)
         g = big_b[:B * hid * N].view(B, hid, H, W)
@@ -252,9 +270,13 @@ class Restormer(nn.Module):
             ops.ln_stats(x, stats)
         ops.gemm1x1(w["pin"], x, h, 2 * hid, C, bias=w["pin_b"], stats=stats, lnw=w["n2w"], lnb=w["n2b"],
                     ln_mode=blk.norm2.mode)
-        ops.dwconv3x3_gate(h, w["ffn_dw"], g, bias=w["ffn_dw_b"])
         emit = fuse and want_stats
-        ops.gemm1x1(w["pout"], g, x, C, hid, res=x, bias=w["pout_b"], stats_out=stats if emit else None)
+        if fuse_dw:
+            ops.dwgemm(w["pout"], w["ffn_dwp"], h, x, C, hid, gate=True, res=x, bias=w["pout_b"],
+                       stats_out=stats if emit else None)
+        else:
+            ops.dwconv3x3_gate(h, w["ffn_dw"], g, bias=w["ffn_dw_b"])
+            ops.gemm1x1(w["pout"], g, x, C, hid, res=x, bias=w["pout_b"], stats_out=stats if emit else None)
         return emit
 
     @staticmethod

@@ -88,6 +88,23 @@ int irm_dwconv3x3_f32(const float* x, long x_bs, const float* w, const float* bi
 int irm_dwconv3x3_gate_f32(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
                            int B, int hid, int H, int W, irm_stream_t stream);
 
+/* Depth-wise 3x3 fused into the 1x1 conv that consumes it (LDS-DMA ring, 8x32 pixel tiles):
+ *   g[k] = gate ? gelu_erf(dw(x[k])) * dw(x[k + K]) : dw(x[k]),   k < K
+ *   y    = W g + bias (+ res),                                     M <= 96, W % 4 == 0, 16-byte aligned
+ * wp: irm_gemm1x1_f32's packed weight (w_bs != 0: one matrix per sample).
+ * dwp: [4*ceil(K/4)][DWS] floats per input channel k (rows beyond K zero), every value stored twice
+ * (v, v) for the packed-fp32 stencil:
+ *   gate:    DWS = 40: taps of channel k (9 pairs), bias[k], taps of channel k+K (9 pairs), bias[k+K]
+ *   no gate: DWS = 20: taps (9 pairs), bias
+ * GELU uses erf from Abramowitz-Stegun 7.1.26 (absolute error <= 1.5e-7).
+ * stats_out: optional [B][2][H*W] LayerNorm statistics of y (as irm_gemm1x1_f32).
+ * gate = 1 replaces FeedForward.dwconv + chunk + gelu(x1)*x2 + project_out (+ the block's residual)
+ * (restormer.py:84-93,148); gate = 0 replaces qkv_dwconv on v + attn @ v + project_out with the folded
+ * matrix of irm_mdta_finalize_f32 (restormer.py:118-131,147). */
+int irm_dwgemm_f32(const float* wp, long w_bs, const float* dwp, const float* x, long x_bs, float* y, long y_bs,
+                   const float* res, long r_bs, const float* bias, int gate, int B, int M, int K, int H, int W,
+                   float* stats_out, float eps, irm_stream_t stream);
+
 /* MDTA pass 1: per-chunk partial Gram matrices and squared norms.
  * qkv: [B][3C][N] (after qkv_dwconv; q rows [0,C), k rows [C,2C)).
  * part: workspace [B][heads][ceil(N/chunk)][c*c + 2c] floats, c = C/heads,

@@ -173,6 +173,52 @@ def test_dwconv3x3_gate(dev, B, hid, H, W):
     assert (y.cpu().double() - ref).abs().max() < TOL
 
 
+DWGEMM_CASES = [
+    # M, K, H, W, B, gate, res, bias, stats, per_batch
+    (48, 127, 19, 36, 2, True, True, False, True, False),
+    (96, 255, 16, 64, 1, True, True, True, True, False),
+    (48, 48, 8, 32, 2, False, True, False, True, True),
+    (96, 96, 21, 40, 1, False, True, True, False, True),
+    (40, 6, 5, 4, 1, True, False, True, False, False),
+    (96, 255, 40, 96, 2, True, True, False, True, False),
+]
+
+
+@pytest.mark.parametrize("M,K,H,W,B,gate,res,bias,stats,per_batch", DWGEMM_CASES)
+def test_dwgemm(dev, M, K, H, W, B, gate, res, bias, stats, per_batch):
+    """Fused depth-wise 3x3 (+ gelu gate) + 1x1 conv (+ residual, + LN statistics of the result)."""
+    kin = 2 * K if gate else K
+    big = rnd(f"dgx{M}{K}{H}", (B, kin + 3, H, W), -1.5, 1.5)
+    x = big.to(dev)[:, 1:1 + kin]
+    w9 = rnd(f"dgw9{K}", (kin, 9), -0.5, 0.5)
+    dwb = rnd(f"dgdb{K}", (kin,), -0.2, 0.2) if bias else None
+    wt = rnd(f"dgw{M}{K}", (B if per_batch else 1, M, K), -0.2, 0.2)
+    pb = rnd(f"dgb{M}", (M,), -0.3, 0.3) if bias else None
+    r = rnd(f"dgr{M}{H}", (B, M, H, W)) if res else None
+    packed = torch.stack([_hip.pack_gemm_weight(wt[i]) for i in range(wt.shape[0])]).to(dev)
+    dwp = _hip.pack_dw_table(w9, dwb, K, gate).to(dev)
+    y = r.clone().to(dev) if res else torch.empty(B, M, H, W, device=dev)      # in place on the residual
+    st = torch.zeros(B, 2, H * W, device=dev) if stats else None
+    ops.dwgemm(packed, dwp, x, y, M, K, gate=gate, res=y if res else None, bias=pb.to(dev) if bias else None,
+               w_bs=packed.shape[1] if per_batch else 0, stats_out=st)
+    xr = big[:, 1:1 + kin].double()
+    d = F.conv2d(xr, w9.double().view(kin, 1, 3, 3), dwb.double() if bias else None, padding=1, groups=kin)
+    g = F.gelu(d[:, :K]) * d[:, K:] if gate else d
+    ref = torch.einsum("bmk,bkhw->bmhw", wt.double().expand(B, M, K), g)
+    if bias:
+        ref = ref + pb.double().view(1, M, 1, 1)
+    if res:
+        ref = ref + r.double()
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err < TOL, err
+    if stats:
+        mean = ref.mean(1).reshape(B, -1)
+        rstd = 1.0 / torch.sqrt(ref.var(1, unbiased=False) + 1e-5).reshape(B, -1)
+        sc = st.cpu().double()
+        assert (sc[:, 0] - mean).abs().max() < 1e-4
+        assert ((sc[:, 1] - rstd).abs() / rstd).max() < 1e-4
+
+
 @pytest.mark.parametrize("B,C,heads,H,W", [(2, 48, 1, 16, 24), (1, 96, 2, 16, 16), (2, 96, 1, 8, 40), (1, 192, 4, 8, 8),
                                            (1, 384, 8, 8, 8), (1, 64, 2, 8, 8), (1, 32, 2, 8, 8), (1, 48, 1, 64, 80), (2, 384, 8, 5, 7), (1, 96, 1, 9, 15)])
 def test_mdta_fold(dev, B, C, heads, H, W):
