@@ -78,6 +78,22 @@ def cpu_baseline(model, frame_u8, gpu_tile, tile_edge):
     return out
 
 
+def pmc_traffic(prefix):
+    """HBM bytes per launch of the kernels whose name starts with prefix, from the committed PMC passes of
+    this same command (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_traffic.py).  None when the file is absent: the
+    counters cannot be read from inside an unprofiled run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "c_fused_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except OSError:
+        return None
+    rows = [v for k, v in d.items() if k.startswith(prefix) and v.get("hbm_bytes_per_launch") is not None]
+    n = sum(v["launches"] for v in rows)
+    return sum(v["launches"] * v["hbm_bytes_per_launch"] for v in rows) / n if n else None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,7 +195,9 @@ def main():
             tfl = g["flops"] / (g["ms"] * 1e-3) / 1e12
             out["roofline"] = {"kernel": "gemm_ring_kernel (irm_gemm1x1_f32)", "bound": "mfma", "achieved": tfl,
                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tfl / PEAK_F32_MFMA_TFLOPS,
-                               "traffic": None, "launches": g["launches"],
+                               "traffic": pmc_traffic("gemm_"), "traffic_unit": "bytes per launch (HBM, PMC)",
+                               "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
+                               "launches": g["launches"],
                                "avg_launch_us": g["ms"] * 1e3 / g["launches"],
                                "share_of_kernel_time": g["ms"] / tot_ms}
             out["kernels"] = {
