@@ -14,7 +14,7 @@ What it does
      the max-abs differences in tests/golden/MANIFEST.json;
   3. stores the REFERENCE outputs (not the oracle's) as golden vectors.
 
-Usage: python oracle/gen_golden.py [--only restormer|tiler|convnets|ops|deblurgan|mair]
+Usage: python oracle/gen_golden.py [--only restormer|tiler|convnets|ops|deblurgan|fullsize|mair]
 """
 from __future__ import annotations
 
@@ -453,6 +453,30 @@ def gen_deblurgan(ref, manifest):
     np.savez_compressed(os.path.join(GOLD, "deblurgan.npz"), **out)
 
 
+def gen_fullsize(ref, manifest):
+    """BASELINE.json configs[1] at its full tile size: the reference Restormer (motion-deblur configuration,
+    synthetic weights seed 42) on tile 0 (512x512) of the benchmark's first synthetic 1280x720 frame.  The
+    fixture keeps every 8th output pixel (49 KB) plus whole-tile moments."""
+    from irm_amd.restormer import restormer as prod
+    kw = RESTORMER_CFGS["deblur_withbias"]
+    net = ref.rmod.Restormer(**kw).eval()
+    sd = synth.synth_state_dict(shapes_of(net), seed=42, rules=prod.SYNTH_RULES)
+    net.load_state_dict(sd, strict=True)
+    inp, _ = synth.synth_image_pair(0, 720, 1280, 3, seed_base=1000, blur=15)
+    x = torch.from_numpy(np.ascontiguousarray(inp[:512, :512].transpose(2, 0, 1))).float().div(255.0)[None]
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        y = net(x)[0].numpy()
+    print(f"fullsize: reference forward on 1x3x512x512 took {time.time() - t0:.0f} s; out range "
+          f"[{y.min():.3f},{y.max():.3f}]")
+    np.savez_compressed(os.path.join(GOLD, "restormer_fullsize.npz"), sub8=y[:, ::8, ::8],
+                        mean=y.mean(axis=(1, 2)), sqmean=(y.astype(np.float64) ** 2).mean(axis=(1, 2)),
+                        row100=y[:, 100, :], in_sha=np.frombuffer(bytes.fromhex(sha(x.numpy())), dtype=np.uint8))
+    manifest["restormer_fullsize"] = {"input": "synth_image_pair(0,720,1280,3,seed_base=1000,blur=15)[0][:512,:512]/255",
+                                      "config": "deblur_withbias", "weights_seed": 42}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -462,7 +486,7 @@ def main():
     manifest = json.load(open(mpath)) if os.path.exists(mpath) else {}
     ref = import_reference()
     steps = {"ops": gen_ops, "restormer": gen_restormer, "convnets": gen_convnets, "tiler": gen_tiler,
-             "deblurgan": gen_deblurgan, "mair": gen_mair}      # mair last: it re-stubs the `mair` package for the reference's arch file
+             "deblurgan": gen_deblurgan, "fullsize": gen_fullsize, "mair": gen_mair}      # mair last: it re-stubs the `mair` package for the reference's arch file
     for k, fn in steps.items():
         if args.only in (None, k):
             fn(ref, manifest)

@@ -1,0 +1,86 @@
+"""Checks at BASELINE.json's full sizes (configs[1]: Restormer motion-deblur on 1280x720 frames, six
+512x512 tiles with overlap 96).
+
+The CPU oracle needs ~1 minute per 512x512 tile on a many-core host, so at this size the tests use
+(a) a golden of the imported reference itself on tile 0 of the benchmark's first frame
+    (tests/golden/restormer_fullsize.npz, written by oracle/gen_golden.py --only fullsize: every 8th output
+    pixel, one full row and whole-tile moments), and
+(b) size-independent properties of the path: run-to-run bit identity, independence of a tile's result from
+    the batch it travels in, the tiler's exact round trip of an identity model, and its bit-exact agreement
+    with the numpy tiler of the oracle on a cheap per-pixel model.
+Tolerances as in BASELINE.json north_star: 1e-3 max-abs on float outputs, integer work bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from irm_amd import restormer, synth, utils
+from oracle import tiler_ref
+
+pytestmark = pytest.mark.gpu
+H, W, PS, OV = 720, 1280, 512, 96
+
+
+@pytest.fixture(scope="module")
+def model(dev):
+    return restormer.Restormer(LayerNorm_type="WithBias").load_synthetic(42).eval().to(dev)
+
+
+@pytest.fixture(scope="module")
+def frame():
+    return synth.synth_image_pair(0, H, W, 3, seed_base=1000, blur=15)      # bench.py's first frame
+
+
+def _tile0(frame, dev):
+    inp = frame[0]
+    return torch.from_numpy(np.ascontiguousarray(inp[:PS, :PS].transpose(2, 0, 1))).float().div(255.0)[None].to(dev)
+
+
+def test_fullsize_tile_vs_reference_golden(dev, model, frame, golden):
+    g = golden("restormer_fullsize")
+    y = model(_tile0(frame, dev))[0].cpu().numpy()
+    err = max(np.abs(y[:, ::8, ::8] - g["sub8"]).max(), np.abs(y[:, 100, :] - g["row100"]).max())
+    m_err = np.abs(y.mean(axis=(1, 2)) - g["mean"]).max()
+    s_err = np.abs((y.astype(np.float64) ** 2).mean(axis=(1, 2)) - g["sqmean"]).max()
+    print(f"512x512 tile vs reference golden: max-abs {err:.3e} on the sampled pixels, channel mean {m_err:.2e}, "
+          f"mean square {s_err:.2e}")
+    assert err <= 1e-3 and m_err <= 1e-5 and s_err <= 1e-5
+
+
+def test_fullsize_batch_independence_and_determinism(dev, model, frame):
+    """Tile 0 alone, tile 0 inside the batch of 6, and a repeated run."""
+    img = torch.from_numpy(frame[0]).to(dev)
+    keep = []
+    out1, _ = utils.tiled_forward_device(model, img, PS, OV, pad8=True, max_batch=8, keep_tiles=keep)
+    preds = keep[0]
+    ys, xs = tiler_ref.tile_origins(H, PS, OV), tiler_ref.tile_origins(W, PS, OV)
+    assert preds.shape == (len(ys) * len(xs), 3, PS, PS) and preds.shape[0] == 6
+    out2, _ = utils.tiled_forward_device(model, img, PS, OV, pad8=True, max_batch=8)
+    assert torch.equal(out1, out2), "same frame twice must give the same bytes"
+    single = model(_tile0(frame, dev))
+    d = float((single - preds[:1]).abs().max())
+    print(f"tile 0 alone vs inside the batch of 6: max-abs {d:.3e}")
+    assert d <= 2e-5
+    # one tile per launch (the reference's loop shape) against the batched launch, after requantisation
+    out3, _ = utils.tiled_forward_device(model, img, PS, OV, pad8=True, max_batch=1)
+    diff = (out1.int() - out3.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3
+
+
+class _PerPixel:
+    """Stand-in model with exactly representable arithmetic: y = 1 - x (correctly rounded on both sides)."""
+    num_streams = 1
+
+    def __call__(self, t):
+        return 1.0 - t
+
+
+def test_fullsize_tiler_round_trip_and_oracle(dev, frame):
+    inp = frame[0]
+    img = torch.from_numpy(inp).to(dev)
+    ident, _ = utils.tiled_forward_device(lambda t: t, img, PS, OV, pad8=True, max_batch=8)
+    assert torch.equal(ident.cpu(), torch.from_numpy(inp)), "identity model: extract -> blend -> requantise is lossless"
+    got, sse = utils.tiled_forward_device(_PerPixel(), img, PS, OV, pad8=True, target_dev=img, max_batch=8)
+    ref = tiler_ref.tiled_inference(lambda t: 1.0 - t, inp, patch_size=PS, patch_overlap=OV, pad=tiler_ref.reflect_pad8)
+    assert np.array_equal(got.cpu().numpy(), ref), "device tiler vs numpy oracle at 1280x720"
+    want = int(((ref.astype(np.int64) - inp.astype(np.int64)) ** 2).sum())
+    assert int(sse.item()) == want, "integer squared error accumulates exactly"
