@@ -133,6 +133,175 @@ __global__ __launch_bounds__(256) void mdta_gram_kernel(GramArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fast path (c = 48 or 96, N % 64 == 0, 16-byte aligned): one workgroup = one (batch, head, chunk of HW) and
+// the whole c x c Gram.  Stages of BP pixels x 2c rows (24 KiB: q rows then k rows of the head) stream through
+// a 3-deep LDS-DMA ring in full 128/256-byte row segments.  Each 1 KiB DMA instruction covers RPB rows; the
+// 16-byte pieces of a row are ROTATED by the row number on the way in (the per-lane source address is
+// free), so that the MFMA operand reads - 16 different rows at the same pixel quad - hit 16 different bank
+// quads: conflict-free ds_read_b32 with one address register per k-step and immediate offsets per tile.
+//   T = 3 (c = 48): BP = 64, the 4 waves split the 16 k-steps of a stage, partial Grams are summed through
+//                   LDS in wave order at the end (deterministic);
+//   T = 6 (c = 96): BP = 32, wave (wa, wb) owns the 48 x 48 quadrant (wa, wb) for all 8 k-steps.
+template <int N>
+__device__ __forceinline__ void gram_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int T, int NS>
+__global__ __launch_bounds__(256, 2) void mdta_gram_ring_kernel(GramArgs a) {
+    constexpr int c = 16 * T;
+    constexpr int BP = T == 3 ? 64 : 32;           // pixels per stage
+    constexpr int CPR = BP / 4;                    // 16-byte pieces per row segment
+    constexpr int RPB = 64 / CPR;                  // rows per 1 KiB DMA instruction
+    constexpr int NI = 2 * c / RPB;                // DMA instructions per stage (24)
+    constexpr int LPS = NI / 4;                    // per wave (6)
+    constexpr int STG = NI * 256;                  // floats per stage
+    constexpr int KS = BP / 4;                     // k-steps per stage
+    static_assert((NS - 2) * LPS <= 63, "vmcnt field");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    const int b = blockIdx.y;
+    const int head = blockIdx.x / a.nchunk, chunk_id = blockIdx.x % a.nchunk;
+    const int nbeg = chunk_id * a.chunk;
+    const int S = (min(nbeg + a.chunk, a.N) - nbeg) / BP;
+    const float* base = a.qkv + (long)b * a.bs + nbeg;
+
+    // DMA sources of this lane: instruction j of this wave covers rows RPB*(4j + wave) ..; lane = rr*CPR + p
+    // fetches piece (p - rot(row)) mod CPR of its row, rot(row) = row mod 16 (T = 3) or (row >> 1) mod 8
+    const float* src[LPS];
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) {
+        const int row = RPB * (4 * j + wave) + lane / CPR, p = lane % CPR;
+        const int rot = (T == 3 ? row : row >> 1) & (CPR - 1);
+        const int ch = row < c ? head * c + row : a.C + head * c + (row - c);
+        src[j] = base + (long)ch * a.N + 4 * ((p - rot) & (CPR - 1));
+    }
+    auto issue = [&](int s) {
+        float* dst = smem + (s % NS) * STG + wave * 256;
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long)s * BP),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+        }
+    };
+
+    // operand reads: row 16m + i (+ c for k), pixel quad ks, element kk
+    //   T = 3: float offset 1024 m + (i>>2)*256 + (i&3)*64 + 4*((ks + i) & 15) + kk        (k rows: + 3072)
+    //   T = 6: float offset  512 m + (i>>3)*256 + (i&7)*32 + 4*((ks + (i>>1)) & 7) + kk    (k rows: + 3072)
+    const int rot = T == 3 ? i : i >> 1;
+    const int lbase = (T == 3 ? (i >> 2) * 256 + (i & 3) * 64 : (i >> 3) * 256 + (i & 7) * 32) + kk;
+    constexpr int MT = T == 3 ? 1024 : 512;        // float stride between 16-row tiles
+    const int wa = wave >> 1, wb = wave & 1;
+    const int qt0 = T == 3 ? 0 : 3 * wa, kt0 = T == 3 ? 0 : 3 * wb;     // first q / k tile of this wave
+    const bool do_q = T == 3 || wa != wb, do_k = T == 3 || wa == wb;    // who accumulates which squared norms
+
+    f32x4 acc[3][3];
+    float nq[3] = {0.f, 0.f, 0.f}, nk[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int y = 0; y < 3; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int j = 0; j < NS - 1; ++j)
+        if (j < S) issue(j);
+
+    for (int s = 0; s < S; ++s) {
+        const int rem = min(NS - 2, S - 1 - s);
+        if (rem >= NS - 2 && NS >= 3) gram_wait_vmcnt<(NS - 2) * LPS>();
+        else gram_wait_vmcnt<0>();
+        asm volatile("s_barrier" ::: "memory");
+        if (s + NS - 1 < S) issue(s + NS - 1);
+        const float* xb = smem + (s % NS) * STG + lbase;
+#pragma unroll
+        for (int t = 0; t < (T == 3 ? KS / 4 : KS); ++t) {
+            const int ks = T == 3 ? 4 * wave + t : t;                   // T = 3: waves split the k-steps
+            const float* pq = xb + 4 * ((ks + rot) & (CPR - 1));
+            float qf[3], kf[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                qf[m] = pq[(qt0 + m) * MT];
+                kf[m] = pq[3072 + (kt0 + m) * MT];
+            }
+            if (do_q) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) nq[m] = fmaf(qf[m], qf[m], nq[m]);
+            }
+            if (do_k) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) nk[m] = fmaf(kf[m], kf[m], nk[m]);
+            }
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+#pragma unroll
+                for (int y = 0; y < 3; ++y) acc[x][y] = irm_mfma16(qf[x], kf[y], acc[x][y]);
+        }
+    }
+
+    // squared norms: sum the 4 pixel slots (lanes i, i+16, i+32, i+48)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        nq[m] += __shfl_xor(nq[m], 16); nq[m] += __shfl_xor(nq[m], 32);
+        nk[m] += __shfl_xor(nk[m], 16); nk[m] += __shfl_xor(nk[m], 32);
+    }
+    constexpr int REC = c * c + 2 * c;
+    float* out = a.part + (((long)b * a.heads + head) * a.nchunk + chunk_id) * REC;
+    if (T == 6) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    out[(long)((qt0 + x) * 16 + kk * 4 + e) * c + (kt0 + y) * 16 + i] = acc[x][y][e];
+        if (kk == 0) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                if (do_q) out[c * c + (qt0 + m) * 16 + i] = nq[m];
+                if (do_k) out[c * c + c + (kt0 + m) * 16 + i] = nk[m];
+            }
+        }
+    } else {
+        // the 4 waves hold partial sums over different k-steps: combine through LDS in wave order
+        asm volatile("s_barrier" ::: "memory");      // every wave is done reading the ring
+        float* mine = smem + wave * REC;
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mine[(x * 16 + kk * 4 + e) * c + y * 16 + i] = acc[x][y][e];
+        if (kk == 0) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                mine[c * c + m * 16 + i] = nq[m];
+                mine[c * c + c + m * 16 + i] = nk[m];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < REC; e += 256)
+            out[e] = ((smem[e] + smem[REC + e]) + smem[2 * REC + e]) + smem[3 * REC + e];
+    }
+}
+
+template <int T>
+static int launch_gram_ring(const GramArgs& a, int B, hipStream_t stream) {
+    constexpr int NS = 3;
+    const size_t lds = (size_t)NS * 24 * 1024;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mdta_gram_ring_kernel<T, NS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return IRM_ELAUNCH;
+        configured = true;
+    }
+    hipLaunchKernelGGL((mdta_gram_ring_kernel<T, NS>), dim3(a.heads * a.nchunk, B), dim3(256), lds, stream, a);
+    return irm_launch_status();
+}
+
 extern "C" int irm_mdta_gram_f32(const float* qkv, long bs, float* part, int B, int C, int heads, int N,
                                  int chunk, hipStream_t stream) {
     if (!qkv || !part || B <= 0 || C <= 0 || heads <= 0 || N <= 0 || chunk <= 0) return IRM_EINVAL;
@@ -140,6 +309,10 @@ extern "C" int irm_mdta_gram_f32(const float* qkv, long bs, float* part, int B, 
     const int c = C / heads;
     if (c % 16) return IRM_EINVAL;
     GramArgs a{qkv, bs, part, C, heads, N, chunk, (N + chunk - 1) / chunk};
+    const bool aligned = !(N & 3) && !(bs & 3) && irm_aligned16(qkv);
+    if (aligned && !(N & 63) && (c == 48 || c == 96) && (long)heads * a.nchunk <= 2147483647L &&
+        !getenv("IRM_GRAM_GENERIC"))
+        return c == 48 ? launch_gram_ring<3>(a, B, stream) : launch_gram_ring<6>(a, B, stream);
     const int sb = (c % 48 == 0) ? 3 : (c % 32 == 0) ? 2 : 1;
     const int nsb = c / (16 * sb);
     const long units = (long)heads * nsb * nsb * a.nchunk;

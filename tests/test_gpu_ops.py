@@ -220,7 +220,8 @@ def test_dwgemm(dev, M, K, H, W, B, gate, res, bias, stats, per_batch):
 
 
 @pytest.mark.parametrize("B,C,heads,H,W", [(2, 48, 1, 16, 24), (1, 96, 2, 16, 16), (2, 96, 1, 8, 40), (1, 192, 4, 8, 8),
-                                           (1, 384, 8, 8, 8), (1, 64, 2, 8, 8), (1, 32, 2, 8, 8), (1, 48, 1, 64, 80), (2, 384, 8, 5, 7), (1, 96, 1, 9, 15)])
+                                           (1, 384, 8, 8, 8), (1, 64, 2, 8, 8), (1, 32, 2, 8, 8), (1, 48, 1, 64, 80), (2, 384, 8, 5, 7), (1, 96, 1, 9, 15),
+                                           (1, 96, 1, 64, 64), (2, 192, 2, 32, 48), (3, 48, 1, 48, 64)])
 def test_mdta_fold(dev, B, C, heads, H, W):
     N, c = H * W, C // heads
     qkv = rnd(f"md{C}{heads}{H}", (B, 3 * C, H, W))
