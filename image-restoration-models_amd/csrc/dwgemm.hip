@@ -32,20 +32,20 @@ __device__ __forceinline__ void dg_wait_vmcnt() {
 }
 
 // LayerNorm statistics of the finished output pixels (same contract as irm_stats_from_acc in gemm_pw.hip):
-// lane (g, j) holds channel 16c + j of 4 pixel quads; pix[q] < 0 marks a quad outside the image.
-template <int CT>
-__device__ __forceinline__ void dg_stats(const float4 (&t)[4][CT], int M, long N, int j, const long (&pix)[4],
+// lane (g, j) holds channel 16c + j of PT pixel quads; pix[q] < 0 marks a quad outside the image.
+template <int CT, int PT>
+__device__ __forceinline__ void dg_stats(const float4 (&t)[PT][CT], int M, long N, int j, const long (&pix)[PT],
                                          float* st, float eps) {
-    float sum[4][4], sq[4][4];
+    float sum[PT][4], sq[PT][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < PT; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sum[q][e] = 0.f; sq[q][e] = 0.f; }
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const bool ok = c * 16 + j < M;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < PT; ++q) {
             const float v[4] = {t[q][c].x, t[q][c].y, t[q][c].z, t[q][c].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) sum[q][e] += ok ? v[e] : 0.f;
@@ -53,7 +53,7 @@ __device__ __forceinline__ void dg_stats(const float4 (&t)[4][CT], int M, long N
     }
     const float inv = 1.0f / (float)M;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < PT; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -64,7 +64,7 @@ __device__ __forceinline__ void dg_stats(const float4 (&t)[4][CT], int M, long N
     for (int c = 0; c < CT; ++c) {
         const bool ok = c * 16 + j < M;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < PT; ++q) {
             const float v[4] = {t[q][c].x, t[q][c].y, t[q][c].z, t[q][c].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -74,7 +74,7 @@ __device__ __forceinline__ void dg_stats(const float4 (&t)[4][CT], int M, long N
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < PT; ++q) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -90,18 +90,19 @@ __device__ __forceinline__ void dg_stats(const float4 (&t)[4][CT], int M, long N
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// Packed-fp32 (v_pk_fma_f32) stencil: 6 rows x 3 columns around 4 vertically neighbouring pixels, the
-// outputs as two register pairs (o0,o1), (o2,o3).  kk[t] holds tap t twice (k,k); bias first, then the
-// taps row by row, as dw_apply in elementwise.hip.  Lanes of a wave read consecutive columns of the halo
-// image: no LDS bank conflicts.
-__device__ __forceinline__ void dg_stencil(const float* img, const v2f (&kk)[9], v2f bias, v2f (&o)[2]) {
-    v2f rp[5][3];                                  // rp[d][dx] = rows d and d+1 at column dx
+// Packed-fp32 (v_pk_fma_f32) stencil: PT+2 rows x 3 columns around PT vertically neighbouring pixels, the
+// outputs as register pairs (o0,o1)[, (o2,o3)].  kk[t] holds tap t twice (k,k); bias first, then the taps row
+// by row, as dw_apply in elementwise.hip.  Lanes of a wave read consecutive columns of the halo image: no LDS
+// bank conflicts.
+template <int PT>
+__device__ __forceinline__ void dg_stencil(const float* img, const v2f (&kk)[9], v2f bias, v2f (&o)[PT / 2]) {
+    v2f rp[PT + 1][3];                             // rp[d][dx] = rows d and d+1 at column dx
 #pragma unroll
-    for (int d = 0; d < 5; ++d)
+    for (int d = 0; d < PT + 1; ++d)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) rp[d][dx] = (v2f){img[d * 40 + dx], img[(d + 1) * 40 + dx]};
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < PT / 2; ++h) {
         v2f s = bias;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
@@ -129,14 +130,17 @@ __device__ __forceinline__ v2f dg_gelu2(v2f x) {
     return sg * h + h;
 }
 
-template <int CT, bool GATE, int NS>
-__global__ __launch_bounds__(256, CT <= 3 ? 3 : 2) void dwgemm_kernel(DwGemmArgs a) {
+// PT = pixels per lane: 4 -> 4 waves, each a 4 x 16 patch; 2 -> 8 waves, each a 2 x 16 patch (half the
+// accumulators per wave: <= 128 VGPRs, 16 waves per CU, for the 96-channel outputs)
+template <int CT, bool GATE, int NS, int PT>
+__global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 2) void dwgemm_kernel(DwGemmArgs a) {
+    constexpr int NT = PT == 4 ? 256 : 512;        // threads per workgroup
     constexpr int NP = GATE ? 8 : 4;               // halo planes per stage
     constexpr int DWS = GATE ? 40 : 20;            // depth-wise coefficients per channel (floats, each twice)
     constexpr int XC = NP * 100, WC = CT * 16;     // 16-byte chunks per stage
     constexpr int TC = XC + WC + DWS;
-    constexpr int R = (TC + 255) / 256;            // DMA instructions per lane per stage
-    constexpr int STG = R * 1024;                  // floats per stage
+    constexpr int R = (TC + NT - 1) / NT;          // DMA instructions per lane per stage
+    constexpr int STG = R * NT * 4;                // floats per stage
     static_assert((NS - 2) * R <= 63, "vmcnt field");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256, CT <= 3 ? 3 : 2) void dwgemm_kernel(DwGemmArgs
     int lim[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const int q = j * 256 + tid;
+        const int q = j * NT + tid;
         base[j] = dg_zero_page; stride[j] = 0; lim[j] = 0;
         if (q < XC) {
             const int pl = q / 100, rem = q - pl * 100, row = rem / 10, chunk = rem - row * 10;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256, CT <= 3 ? 3 : 2) void dwgemm_kernel(DwGemmArgs
             const float* src = (tail && s >= lim[j]) ? dg_zero_page : base[j];
             base[j] += stride[j];
             if (!(a.dbg & 1)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + j * NT * 4), 16, 0, 0);
         }
     };
 
@@ -204,24 +208,24 @@ __global__ __launch_bounds__(256, CT <= 3 ? 3 : 2) void dwgemm_kernel(DwGemmArgs
     for (int j = 0; j < NS - 1; ++j)
         if (j < S) issue(j);
 
-    // accumulators start from bias + residual: lane (g, i) holds channel 16c + i of the pixel quads q = 0..3,
-    // row 4*(wave>>1) + q, columns 16*(wave&1) + 4*g + [0,4)
+    // accumulators start from bias + residual: lane (g, i) holds channel 16c + i of the pixel quads q < PT,
+    // row PT*(wave>>1) + q, columns 16*(wave&1) + 4*g + [0,4)
     float* Y = a.Y + (long)b * a.y_bs;
     const float* Rp = a.R ? a.R + (long)b * a.r_bs : nullptr;
-    long pix[4];
+    long pix[PT];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int y = ty0 + (wave >> 1) * 4 + q, x = tx0 + 16 * (wave & 1) + 4 * g;
+    for (int q = 0; q < PT; ++q) {
+        const int y = ty0 + (wave >> 1) * PT + q, x = tx0 + 16 * (wave & 1) + 4 * g;
         pix[q] = (y < a.H && x < a.W) ? (long)y * a.W + x : -1;
     }
-    f32x4 acc[4][CT];
+    f32x4 acc[PT][CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int co = c * 16 + i;
         const bool row_ok = co < a.M;
         const float bv = (a.bias && row_ok) ? a.bias[co] : 0.0f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < PT; ++q) {
             float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
             if (Rp) {       // unconditional (clamped) loads: all of them are in flight together
                 const bool ok = row_ok && pix[q] >= 0;
@@ -232,9 +236,9 @@ __global__ __launch_bounds__(256, CT <= 3 ? 3 : 2) void dwgemm_kernel(DwGemmArgs
         }
     }
 
-    // A-operand pixels of this lane: column 16*(wave&1) + i, rows 4*(wave>>1) + p, p = 0..3 (a wave owns a
-    // 4 x 16 patch); img_off = top-left tap of the first pixel in the halo image
-    const int img_off = g * 400 + (wave >> 1) * 160 + 16 * (wave & 1) + i + 3;
+    // A-operand pixels of this lane: column 16*(wave&1) + i, rows PT*(wave>>1) + p, p < PT (a wave owns a
+    // PT x 16 patch); img_off = top-left tap of the first pixel in the halo image
+    const int img_off = g * 400 + (wave >> 1) * (PT * 40) + 16 * (wave & 1) + i + 3;
 
     for (int s = 0; s < S; ++s) {
         const int rem = min(NS - 2, S - 1 - s);
@@ -247,21 +251,22 @@ __global__ __launch_bounds__(256, CT <= 3 ? 3 : 2) void dwgemm_kernel(DwGemmArgs
         const float* xb = smem + (s % NS) * STG;
         const float* wb = xb + XC * 4;
         const v2f* dk = reinterpret_cast<const v2f*>(wb + WC * 4 + g * DWS);
-        float af[4];
+        float af[PT];
         {
-            v2f ka[9], oa[2];
+            v2f ka[9], oa[PT / 2];
 #pragma unroll
             for (int t = 0; t < 9; ++t) ka[t] = dk[t];
-            dg_stencil(xb + img_off, ka, dk[9], oa);
+            dg_stencil<PT>(xb + img_off, ka, dk[9], oa);
             if (GATE) {
-                v2f kb[9], ob[2];
+                v2f kb[9], ob[PT / 2];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) kb[t] = dk[10 + t];
-                dg_stencil(xb + img_off + 1600, kb, dk[19], ob);
+                dg_stencil<PT>(xb + img_off + 1600, kb, dk[19], ob);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) oa[h] = dg_gelu2(oa[h]) * ob[h];
+                for (int h = 0; h < PT / 2; ++h) oa[h] = dg_gelu2(oa[h]) * ob[h];
             }
-            af[0] = oa[0].x; af[1] = oa[0].y; af[2] = oa[1].x; af[3] = oa[1].y;
+            #pragma unroll
+            for (int h = 0; h < PT / 2; ++h) { af[2 * h] = oa[h].x; af[2 * h + 1] = oa[h].y; }
         }
         // (the f32 MFMA shares the SIMD's fp32 datapath with the VALU: interleaving the two streams inside
         // a wave or across waves buys nothing, the kernel costs VALU + MFMA time)
@@ -271,54 +276,42 @@ __global__ __launch_bounds__(256, CT <= 3 ? 3 : 2) void dwgemm_kernel(DwGemmArgs
 #pragma unroll
         for (int c = 0; c < CT; ++c)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) acc[p][c] = irm_mfma16(af[p], bf[c], acc[p][c]);
-        // all LDS reads of the stage first (one latency instead of five with 2 waves per SIMD), then the
-        // vector work, then the matrix work
-        __builtin_amdgcn_sched_group_barrier(0x100, 80, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 400, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * CT, 0);
+            for (int p = 0; p < PT; ++p) acc[p][c] = irm_mfma16(af[p], bf[c], acc[p][c]);
     }
 
-    float4 t[4][CT];
+    float4 t[PT][CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t[q][c] = make_float4(acc[q][c][0], acc[q][c][1], acc[q][c][2], acc[q][c][3]);
-    if (a.stats_out) dg_stats<CT>(t, a.M, plane, i, pix, a.stats_out + (long)b * 2 * plane, a.eps);
+        for (int q = 0; q < PT; ++q) t[q][c] = make_float4(acc[q][c][0], acc[q][c][1], acc[q][c][2], acc[q][c][3]);
+    if (a.stats_out) dg_stats<CT, PT>(t, a.M, plane, i, pix, a.stats_out + (long)b * 2 * plane, a.eps);
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int co = c * 16 + i;
         if (co >= a.M) continue;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < PT; ++q)
             if (pix[q] >= 0) *reinterpret_cast<float4*>(Y + (long)co * plane + pix[q]) = t[q][c];
     }
 }
 
-template <int CT, bool GATE, int NS>
-static int dg_launch_ns(const DwGemmArgs& a, int B, hipStream_t stream) {
+template <int CT, bool GATE, int PT>
+static int dg_launch(const DwGemmArgs& a, int B, hipStream_t stream) {
+    constexpr int NS = 3;                          // deeper rings (4..6) measured no faster: occupancy matters more
+    constexpr int NT = PT == 4 ? 256 : 512;
     constexpr int TC = (GATE ? 800 : 400) + CT * 16 + (GATE ? 40 : 20);
-    constexpr int R = (TC + 255) / 256;
-    const size_t lds = (size_t)NS * R * 4096;
+    constexpr int R = (TC + NT - 1) / NT;
+    const size_t lds = (size_t)NS * R * NT * 16;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgemm_kernel<CT, GATE, NS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgemm_kernel<CT, GATE, NS, PT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return IRM_ELAUNCH;
         configured = true;
     }
     const int per = (a.tiles + 7) >> 3;
-    hipLaunchKernelGGL((dwgemm_kernel<CT, GATE, NS>), dim3(per * 8, B), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((dwgemm_kernel<CT, GATE, NS, PT>), dim3(per * 8, B), dim3(NT), lds, stream, a);
     return irm_launch_status();
-}
-
-template <int CT, bool GATE>
-static int dg_launch(const DwGemmArgs& a, int B, hipStream_t stream) {
-    static const int ns = [] { const char* e = getenv("IRM_DWGEMM_NS"); return e ? atoi(e) : 0; }();
-    if (ns == 4) return dg_launch_ns<CT, GATE, 4>(a, B, stream);
-    if (ns == 5) return dg_launch_ns<CT, GATE, 5>(a, B, stream);
-    if (ns == 6) return dg_launch_ns<CT, GATE, 6>(a, B, stream);
-    return dg_launch_ns<CT, GATE, 3>(a, B, stream);
 }
 
 extern "C" int irm_dwgemm_f32(const float* wp, long w_bs, const float* dwp, const float* x, long x_bs, float* y,
@@ -337,6 +330,12 @@ extern "C" int irm_dwgemm_f32(const float* wp, long w_bs, const float* dwp, cons
     a.tiles_x = (W + 31) / 32;
     a.tiles = a.tiles_x * ((H + 7) / 8);
     { const char* e = getenv("IRM_DWGEMM_DBG"); a.dbg = e ? atoi(e) : 0; }
-    if (a.mtiles <= 3) return gate ? dg_launch<3, true>(a, B, stream) : dg_launch<3, false>(a, B, stream);
-    return gate ? dg_launch<6, true>(a, B, stream) : dg_launch<6, false>(a, B, stream);
+    static const int pt_env = [] { const char* e = getenv("IRM_DWGEMM_PT"); return e ? atoi(e) : 0; }();
+    const int pt = pt_env == 2 ? 2 : 4;      // 8 waves x 2 pixels: twice the occupancy, measured no faster
+    if (a.mtiles <= 3) {
+        if (pt == 4) return gate ? dg_launch<3, true, 4>(a, B, stream) : dg_launch<3, false, 4>(a, B, stream);
+        return gate ? dg_launch<3, true, 2>(a, B, stream) : dg_launch<3, false, 2>(a, B, stream);
+    }
+    if (pt == 4) return gate ? dg_launch<6, true, 4>(a, B, stream) : dg_launch<6, false, 4>(a, B, stream);
+    return gate ? dg_launch<6, true, 2>(a, B, stream) : dg_launch<6, false, 2>(a, B, stream);
 }
