@@ -83,7 +83,7 @@ def pmc_traffic(prefix):
     this same command (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_traffic.py).  None when the file is absent: the
     counters cannot be read from inside an unprofiled run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "c_fused_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "d_final_pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
