@@ -32,6 +32,7 @@ SIGNATURES = {
     "irm_conv3x3_f32": [_P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "irm_tile_extract": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "irm_chan_stats_f32": [_P, _L, _P, _I, _I, _I, _F, _P],
+    "irm_chan_stats_ws_f32": [_P, _L, _P, _P, _L, _I, _I, _I, _F, _P],
     "irm_chan_norm_act_f32": [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P],
     "irm_conv3x3_s2_f32": [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _P],
     "irm_dwconv3x3_s2_f32": [_P, _L, _P, _P, _L, _I, _I, _I, _I, _P],

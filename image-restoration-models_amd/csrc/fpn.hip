@@ -45,6 +45,100 @@ extern "C" int irm_chan_stats_f32(const float* x, long x_bs, float* stats, int B
     return irm_launch_status();
 }
 
+// ---------------------------------------------------------------------------
+// Large planes (a 1280x720 frame is ONE tile for this model): split every plane over several workgroups.
+// Each thread folds 16-element register chunks (exact two-pass mean / M2 per chunk) into a running
+// (n, mean, M2) triple with Chan's merge; lanes, waves and finally the slices are merged in a fixed order,
+// so the result does not depend on scheduling.  ws: [B*C][nsplit][3] floats.
+struct WF { float n, mean, m2; };
+__device__ __forceinline__ WF wf_merge(WF a, WF b) {
+    const float n = a.n + b.n;
+    if (n == 0.0f) return a;
+    const float d = b.mean - a.mean, f = b.n / n;
+    WF r;
+    r.n = n;
+    r.mean = fmaf(d, f, a.mean);
+    r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ ws,
+                                                           int C, int N, int nsplit) {
+    __shared__ WF sh[4];
+    const int sp = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+    const float4* p = reinterpret_cast<const float4*>(x + (long)b * x_bs + (long)c * N);
+    const int nv = N >> 2;                                   // float4 units (N % 4 == 0 on this path)
+    const int per = ((nv + nsplit - 1) / nsplit + 3) & ~3;   // units per slice, multiple of 4
+    const int beg = sp * per, end = min(beg + per, nv);
+    WF acc{0.f, 0.f, 0.f};
+    for (int i = beg + threadIdx.x * 4; i < end; i += 1024) {
+        float v[16];
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i + j < end) {
+                const float4 t = p[i + j];
+                v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+                cnt += 4;
+            } else {
+                v[4 * j] = v[4 * j + 1] = v[4 * j + 2] = v[4 * j + 3] = 0.0f;
+            }
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += v[j];
+        WF ch;
+        ch.n = (float)cnt;
+        ch.mean = s / ch.n;
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const float d = v[j] - ch.mean; q += j < cnt ? d * d : 0.0f; }
+        ch.m2 = q;
+        acc = wf_merge(acc, ch);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        WF other;
+        other.n = __shfl_xor(acc.n, o); other.mean = __shfl_xor(acc.mean, o); other.m2 = __shfl_xor(acc.m2, o);
+        // same operand order on both partners: the lower lane is always the left operand
+        acc = (threadIdx.x & o) ? wf_merge(other, acc) : wf_merge(acc, other);
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const WF r = wf_merge(wf_merge(sh[0], sh[1]), wf_merge(sh[2], sh[3]));
+        float* o = ws + (((long)b * C + c) * nsplit + sp) * 3;
+        o[0] = r.n; o[1] = r.mean; o[2] = r.m2;
+    }
+}
+
+__global__ __launch_bounds__(64) void chan_finish_kernel(const float* __restrict__ ws, float* __restrict__ st, int planes,
+                                                         int nsplit, float eps) {
+    const int pl = blockIdx.x * 64 + threadIdx.x;
+    if (pl >= planes) return;
+    const float* w = ws + (long)pl * nsplit * 3;
+    WF acc{w[0], w[1], w[2]};
+    for (int i = 1; i < nsplit; ++i) acc = wf_merge(acc, WF{w[3 * i], w[3 * i + 1], w[3 * i + 2]});
+    st[(long)pl * 2] = acc.mean;
+    st[(long)pl * 2 + 1] = 1.0f / sqrtf(acc.m2 / acc.n + eps);
+}
+
+extern "C" int irm_chan_stats_ws_f32(const float* x, long x_bs, float* stats, float* ws, long ws_floats, int B, int C,
+                                     int N, float eps, hipStream_t stream) {
+    if (!x || !stats || B <= 0 || C <= 0 || N <= 0 || B > 65535 || C > 65535) return IRM_EINVAL;
+    // slices per plane: about 1024 workgroups in total, at least 4096 elements each
+    int nsplit = (1024 + B * C - 1) / (B * C);
+    nsplit = min(nsplit, max(N / 4096, 1));
+    const bool vec = !(N & 3) && !(x_bs & 3) && irm_aligned16(x);
+    if (nsplit <= 1 || !vec || !ws || ws_floats < (long)B * C * nsplit * 3)
+        return irm_chan_stats_f32(x, x_bs, stats, B, C, N, eps, stream);
+    hipLaunchKernelGGL(chan_partial_kernel, dim3(nsplit, C, B), dim3(256), 0, stream, x, x_bs, ws, C, N, nsplit);
+    int rc = irm_launch_status();
+    if (rc != IRM_OK) return rc;
+    hipLaunchKernelGGL(chan_finish_kernel, dim3((B * C + 63) / 64), dim3(64), 0, stream, ws, stats, B * C, nsplit, eps);
+    return irm_launch_status();
+}
+
 // y = act((x - mean) * rstd * w[c] + b[c]) (+ res); w, b optional (InstanceNorm2d(affine=False)); in place ok
 __global__ __launch_bounds__(256) void chan_norm_act_kernel(const float* __restrict__ x, long x_bs,
                                                             const float* __restrict__ st, const float* __restrict__ w,

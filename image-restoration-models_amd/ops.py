@@ -247,12 +247,22 @@ def losh_combine(ysum, gw, gb, gate, yT, nw, nb, z, out, B, L, D, nchunk, eps=1e
 
 
 # --------------------------------------------------------------------------- DeblurGANv2 FPN-MobileNet
+_STATS_WS = {}
+
+
 def chan_stats(x, stats, eps=1e-5):
-    """stats[b, c] = (mean, rstd) over H*W (train-mode BatchNorm on one tile / InstanceNorm)."""
+    """stats[b, c] = (mean, rstd) over H*W (train-mode BatchNorm on one tile / InstanceNorm).  Large planes
+    are split over several workgroups; the partials live in a per-stream workspace."""
     _chk(x, "x")
     B, C, H, W = x.shape
-    _launch("chan_stats", 4.0 * B * C * H * W, 4.0 * B * C * H * W, "irm_chan_stats_f32", _hip.ptr(x), _bs(x),
-            _hip.ptr(stats), B, C, H * W, float(eps), tag=f"C{C} {H}x{W} B{B}")
+    need = 3 * B * C * (-(-1024 // (B * C)))
+    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    ws = _STATS_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 8192), dtype=torch.float32, device=x.device)
+        _STATS_WS[key] = ws
+    _launch("chan_stats", 4.0 * B * C * H * W, 4.0 * B * C * H * W, "irm_chan_stats_ws_f32", _hip.ptr(x), _bs(x),
+            _hip.ptr(stats), _hip.ptr(ws), ws.numel(), B, C, H * W, float(eps), tag=f"C{C} {H}x{W} B{B}")
 
 
 def chan_norm_act(x, stats, y, *, weight=None, bias=None, res=None, act=ACT_NONE):

@@ -166,6 +166,11 @@ int irm_window_blend(const float* pred, const int* origins, const float* window,
  * stats[b][c] = {mean, 1/sqrt(biased var + eps)} over the H*W plane: BatchNorm2d in train mode on one
  * tile (mobilenet_v2.py:5-57 with deblurganv2/__init__.py:38) and InstanceNorm2d (fpn_mobilenet.py:96-104). */
 int irm_chan_stats_f32(const float* x, long x_bs, float* stats, int B, int C, int N, float eps, irm_stream_t stream);
+/* Same result contract with a caller-provided workspace (ws_floats >= 3 * B * C * ceil(1024 / (B*C)) floats is
+ * always enough): large planes are split over several workgroups and merged in a fixed order (Chan's
+ * parallel variance).  Falls back to the single-workgroup kernel when the planes are small or unaligned. */
+int irm_chan_stats_ws_f32(const float* x, long x_bs, float* stats, float* ws, long ws_floats, int B, int C, int N,
+                          float eps, irm_stream_t stream);
 /* y = act((x - mean) * rstd * w[c] + b[c]) (+ res); w, b may be NULL (affine=False); act 0 none, 1 ReLU,
  * 4 ReLU6; in place allowed.  The residual is the InvertedResidual skip (mobilenet_v2.py:52-56). */
 int irm_chan_norm_act_f32(const float* x, long x_bs, const float* stats, const float* w, const float* b,

@@ -38,6 +38,25 @@ def test_chan_norm(dev, B, C, H, W, act, res, affine):
     assert (xg.cpu().double() - ref).abs().max() < TOL
 
 
+@pytest.mark.parametrize("B,C,H,W,lo,hi", [(1, 8, 96, 128, -2.0, 3.0), (1, 3, 200, 324, 100.0, 101.0),
+                                            (2, 32, 360, 640, -1.0, 1.0), (1, 5, 37, 51, 0.0, 1.0)])
+def test_chan_stats_split_planes(dev, B, C, H, W, lo, hi):
+    """Planes large enough to be split over several workgroups (and a large common offset): mean / rstd
+    against float64, and bit-identical on a second run."""
+    x = rnd(f"cs{C}{H}", (B, C, H, W), lo, hi)
+    xg = x.to(dev)
+    st, st2 = torch.empty(B, C, 2, device=dev), torch.empty(B, C, 2, device=dev)
+    ops.chan_stats(xg, st)
+    ops.chan_stats(xg, st2)
+    assert torch.equal(st, st2)
+    xd = x.double().reshape(B, C, -1)
+    mean, var = xd.mean(-1), xd.var(-1, unbiased=False)
+    got = st.cpu().double()
+    assert (got[..., 0] - mean).abs().max() < 1e-5 * max(1.0, abs(hi))
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    assert ((got[..., 1] - rstd).abs() / rstd).max() < 1e-4
+
+
 @pytest.mark.parametrize("H,W", [(32, 48), (23, 41)])
 def test_stride2_convs(dev, H, W):
     x = rnd("s2x", (2, 3, H, W))
