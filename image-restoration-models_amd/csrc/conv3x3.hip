@@ -51,6 +51,12 @@ struct ConvArgs {
 template <int CT>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     __shared__ float xs[2][CV_CK * CV_PLANE];
+    // packed weights of one stage (9 taps x CT tiles x 2 k-steps x 64 lanes), double buffered like xs: read
+    // from global once per stage with coalesced loads instead of one dependent load per tap inside the MFMA loop
+    constexpr int WST = 9 * CT * 2 * 64;
+    __shared__ float wsm[2][WST];
+    constexpr int WLOAD = (WST + 255) / 256;
+    float wr[WLOAD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z;
     const int ty0 = (blockIdx.x / a.tiles_x) * CV_TH;
@@ -96,18 +102,40 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     for (int chunk = blockIdx.y; chunk < nchunks; chunk += gridDim.y) {
         const int mt0 = chunk * CT;
         const int nct = min(CT, a.mtiles - mt0);
+        auto load_w = [&](int s) {
+#pragma unroll
+            for (int j = 0; j < WLOAD; ++j) {
+                const int e = tid + j * 256;                   // ((tap * CT + c) * 2 + kk) * 64 + lane
+                float v = 0.0f;
+                if (e < WST) {
+                    const int ln = e & 63, kk = (e >> 6) & 1, tc = e >> 7, c = tc % CT, tap = tc / CT;
+                    if (c < nct) v = a.Wp[(((long)tap * a.mtiles + mt0 + c) * a.ksteps + s * 2 + kk) * 64 + ln];
+                }
+                wr[j] = v;
+            }
+        };
+        auto store_w = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < WLOAD; ++j) {
+                const int e = tid + j * 256;
+                if (e < WST) wsm[buf][e] = wr[j];
+            }
+        };
         f32x4 acc[4][CT];
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        __syncthreads();                      // the previous chunk is done with both buffers
         load_stage(0);
+        load_w(0);
         store_stage(0);
+        store_w(0);
         __syncthreads();
         for (int s = 0; s < nstages; ++s) {
             const int buf = s & 1;
-            if (s + 1 < nstages) load_stage(s + 1);
+            if (s + 1 < nstages) { load_stage(s + 1); load_w(s + 1); }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int dy = tap / 3, dx = tap % 3;
@@ -115,11 +143,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
                 for (int kk = 0; kk < 2; ++kk) {
                     float bf[CT], af[4];
 #pragma unroll
-                    for (int c = 0; c < CT; ++c) {
-                        const int mt = mt0 + c;
-                        bf[c] = (c < nct)
-                            ? a.Wp[(((long)tap * a.mtiles + mt) * a.ksteps + s * 2 + kk) * 64 + lane] : 0.0f;
-                    }
+                    for (int c = 0; c < CT; ++c) bf[c] = wsm[buf][((tap * CT + c) * 2 + kk) * 64 + lane];
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         const int yy = wave * 2 + (p >> 1) + dy;
@@ -135,7 +159,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
                     }
                 }
             }
-            if (s + 1 < nstages) store_stage(buf ^ 1);
+            if (s + 1 < nstages) { store_stage(buf ^ 1); store_w(buf ^ 1); }
             __syncthreads();
         }
 

@@ -200,11 +200,16 @@ def conv3x3(wp, x, y, ci: int, co: int, *, bias=None, relu1=False, res=None, res
     _chk(x, "x"), _chk(y, "y")
     B, _, H, W = x.shape
     mt = (co + 15) // 16
+    blocks = -(-W // 32) * -(-H // 8) * B
     if ct is None:
         ct = _hip.choose_ct(mt, (6, 4, 3, 2, 1))
+        # small images (FPN levels, level-4 tiles): fewer output tiles per workgroup so that the chip is filled
+        for smaller in (4, 3, 2, 1):
+            if blocks * -(-mt // ct) >= 256 or smaller >= ct:
+                continue
+            ct = smaller
     if ygroups is None:
         nchunks = -(-mt // ct)
-        blocks = -(-W // 32) * -(-H // 8) * B
         ygroups = max(1, min(nchunks, -(-target_blocks() // blocks)))
     nbytes = 4.0 * B * H * W * (ci + co + (co if res is not None else 0))
     _launch("conv3x3", 18.0 * B * ci * co * H * W, nbytes, "irm_conv3x3_f32", _hip.ptr(wp), _hip.ptr(x), _bs(x),

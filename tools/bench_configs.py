@@ -93,7 +93,7 @@ def workloads(dev):
     return w
 
 
-def run(key, spec, steps, warm, dev, cpu):
+def run(key, spec, steps, warm, dev, cpu, detail=None):
     model, img, tk = spec["model"], spec["img"], spec["tiler"]
     img_dev = torch.from_numpy(img).to(dev)
     mb = getattr(model, "max_tiles_per_batch", 8)
@@ -104,7 +104,7 @@ def run(key, spec, steps, warm, dev, cpu):
     for _ in range(warm):
         step()
     torch.cuda.synchronize()
-    timer = ops.KernelTimer()
+    timer = ops.KernelTimer(detail=detail is not None)
     ops.TIMER = timer
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -112,6 +112,12 @@ def run(key, spec, steps, warm, dev, cpu):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     ops.TIMER = None
+    if detail:
+        rows = {k: {"launches": v["launches"], "us_per_launch": v["ms"] * 1e3 / v["launches"], "ms_per_step": v["ms"] / steps,
+                    "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12, "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9}
+                for k, v in timer.summary().items()}
+        with open(detail, "w") as f:
+            json.dump(dict(sorted(rows.items(), key=lambda kv: -kv[1]["ms_per_step"])), f, indent=1)
     agg = {}
     for k, v in timer.summary().items():
         d = agg.setdefault(k.split(" ")[0], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
@@ -167,13 +173,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--detail", default=None, help="per-shape kernel table (json) of the LAST workload run")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     table = workloads(dev)
     lines = []
     for key in (args.which or list(table)):
         spec = table[key]()
-        res = run(key, spec, args.steps, args.warmup, dev, not args.no_cpu_baseline)
+        res = run(key, spec, args.steps, args.warmup, dev, not args.no_cpu_baseline, args.detail)
         line = json.dumps(res)
         print(line, flush=True)
         lines.append(line)
