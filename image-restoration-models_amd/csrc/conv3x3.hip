@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(ConvArgs a) {
     static_assert((NS - 2) * LPS <= 63, "vmcnt field");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, r = lane & 15;
     const int b = blockIdx.z;
     const int ty0 = (blockIdx.x / a.tiles_x) * CV_TH;

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
     static_assert((NS - 2) * R <= 63, "vmcnt field");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
     const int b = blockIdx.y;
     // neighbouring tiles share halo rows: keep runs of consecutive tiles on one XCD (blocks are dealt

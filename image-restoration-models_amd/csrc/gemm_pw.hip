@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
     static_assert((NS - 2) * LPS + NST <= 63, "vmcnt field");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: address math on the SALU
     const int g = lane >> 4, r = lane & 15;
     const int b = blockIdx.z;
     const int n0 = blockIdx.x * BN;
@@ -325,16 +325,22 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
 
     const int xrow = wave * PT * RPU + (lane * 4) / BN;        // + j * RPU
     const int xcol = min(n0 + (lane * 4) % BN, a.N - 4);
+    // per-lane source of row xrow; stages and the PT rows of a wave are uniform offsets from it (the VALU
+    // shares its datapath with the f32 MFMA: two adds per DMA instead of a clamp and a 64-bit multiply-add)
+    const float* xlane = X + (long)xrow * a.N + xcol;
+    const bool ragged = (a.K % BK) != 0;                       // only then can a row index pass K - 1
 
     auto issue = [&](int it) {
         if (a.dbg & 1) return;
         const int ci = it / S, s = it - ci * S;
         const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
         float* xb = smem + (it % NS) * STG;
+        const bool tail = ragged && s == S - 1;
+        const float* sbase = xlane + (long)s * BK * a.N;
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
-            const int k = min(s * BK + xrow + j * RPU, a.K - 1);
-            const float* src = X + (long)k * a.N + xcol;
+            const float* src = sbase + (long)(j * RPU) * a.N;
+            if (tail) src = X + (long)min(s * BK + xrow + j * RPU, a.K - 1) * a.N + xcol;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(xb + (wave * PT + j) * 256),
                                              16, 0, 0);

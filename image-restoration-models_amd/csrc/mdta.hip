@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void mdta_gram_ring_kernel(GramArgs a) {
     static_assert((NS - 2) * LPS <= 63, "vmcnt field");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kk = lane >> 4;
     const int b = blockIdx.y;
     const int head = blockIdx.x / a.nchunk, chunk_id = blockIdx.x % a.nchunk;
