@@ -14,7 +14,7 @@ What it does
      the max-abs differences in tests/golden/MANIFEST.json;
   3. stores the REFERENCE outputs (not the oracle's) as golden vectors.
 
-Usage: python oracle/gen_golden.py [--only restormer|tiler|convnets|ops|deblurgan|fullsize|mair]
+Usage: python oracle/gen_golden.py [--only restormer|tiler|convnets|ops|deblurgan|fullsize|demo|mair]
 """
 from __future__ import annotations
 
@@ -477,6 +477,35 @@ def gen_fullsize(ref, manifest):
                                       "config": "deblur_withbias", "weights_seed": 42}
 
 
+def gen_demo(ref, manifest):
+    """BASELINE.json configs[0]: the reference's CPU-runnable demo case (scripts/test_demo.py) - DnCNN gray
+    Gaussian sigma 25 on its 256x256 demo image, through the reference's own get_patch_config +
+    get_model_prediction on the CPU.  The checkpoints are not available offline, so the network carries the
+    synthetic weights (seed 42); the image is the reference's data file demo/denoising_gaussian_gray_blind_noisy.bmp
+    (already noisy: no degradation is added), stored in the fixture as a uint8 array."""
+    from PIL import Image
+    from irm_amd.dncnn import SYNTH_RULES as DN_RULES
+    U = ref.utils
+    img = np.array(Image.open(os.path.join(os.path.dirname(REF_SRC), "demo", "denoising_gaussian_gray_blind_noisy.bmp")).convert("L"))
+    assert img.shape == (256, 256) and img.dtype == np.uint8
+    img = img[:, :, None]
+    out = {"noisy_u8": img}
+    for tag, nb in (("nonblind_nb17", 17), ("blind_nb20", 20)):
+        net = ref.dncnn.DnCNN(in_nc=1, out_nc=1, nc=64, nb=nb, act_mode="R").eval()
+        sd = synth.synth_state_dict(shapes_of(net), seed=42, rules=DN_RULES)
+        net.load_state_dict(sd)
+        cfg = U.get_patch_config("denoising", "gaussian", "DnCNN")
+        pred, _ = U.get_model_prediction(net, img, torch.device("cpu"), **cfg)
+        orc = tiler_ref.tiled_inference(lambda t: convnets_ref.dncnn_forward(t, sd), img,
+                                        patch_size=cfg["patch_size"], patch_overlap=cfg["patch_overlap"])
+        nd = int((pred.astype(int) != orc.astype(int)).sum())
+        manifest.setdefault("oracle_vs_reference", {})[f"demo/{tag}/u8_mismatches"] = nd
+        print(f"demo {tag}: patch config {cfg}, u8 mismatches oracle-vs-reference {nd} of {pred.size}")
+        assert nd == 0
+        out[tag] = pred
+    np.savez_compressed(os.path.join(GOLD, "demo_c1.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -486,7 +515,7 @@ def main():
     manifest = json.load(open(mpath)) if os.path.exists(mpath) else {}
     ref = import_reference()
     steps = {"ops": gen_ops, "restormer": gen_restormer, "convnets": gen_convnets, "tiler": gen_tiler,
-             "deblurgan": gen_deblurgan, "fullsize": gen_fullsize, "mair": gen_mair}      # mair last: it re-stubs the `mair` package for the reference's arch file
+             "deblurgan": gen_deblurgan, "fullsize": gen_fullsize, "demo": gen_demo, "mair": gen_mair}      # mair last: it re-stubs the `mair` package for the reference's arch file
     for k, fn in steps.items():
         if args.only in (None, k):
             fn(ref, manifest)

@@ -68,6 +68,17 @@ def test_oracle_tiler_vs_golden(golden, manifest):
     assert np.array_equal(tiler_ref.degrade(tl, 25), golden("tiler")["noise_40x48x3_s25"])
 
 
+def test_oracle_demo_case_vs_golden(golden, manifest):
+    """BASELINE.json configs[0]: the reference's CPU demo case (DnCNN gray on its 256x256 demo image through
+    get_patch_config + get_model_prediction, synthetic weights) - oracle tiler + oracle DnCNN, u8 exact."""
+    g = golden("demo_c1")
+    shapes = {k: tuple(v) for k, v in manifest["dncnn_param_shapes"]["gray17"].items()}
+    sd = synth.synth_state_dict(shapes, seed=42, rules=dncnn.SYNTH_RULES)
+    pred = tiler_ref.tiled_inference(lambda t: convnets_ref.dncnn_forward(t, sd), g["noisy_u8"], patch_size=256,
+                                     patch_overlap=48)
+    assert np.array_equal(pred, g["nonblind_nb17"])
+
+
 def test_selective_scan_oracle_vs_independent_float64():
     """The scan op is unpinned by any reference artefact (mamba_ssm is absent): cross-check the oracle's
     fp32 restatement against an independent float64 evaluation written from the published recurrence."""

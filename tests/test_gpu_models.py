@@ -231,6 +231,19 @@ def test_tiled_dncnn_vs_golden(dev, golden, tag, kw):
     assert diff.max() <= 1 and (diff > 0).mean() < 0.01
 
 
+@pytest.mark.parametrize("tag,nb", [("nonblind_nb17", 17), ("blind_nb20", 20)])
+def test_demo_case_vs_reference_golden(dev, golden, tag, nb):
+    """BASELINE.json configs[0] (scripts/test_demo.py): DnCNN gray on the reference's 256x256 demo image through
+    get_patch_config + get_model_prediction; golden = the reference's own functions on the CPU (synthetic weights)."""
+    g = golden("demo_c1")
+    model = dncnn.DnCNN(1, 1, 64, nb, "R").load_synthetic(42).eval().to(dev)
+    cfg = utils.get_patch_config("denoising", "gaussian", "DnCNN")
+    pred, ms = utils.get_model_prediction(model, g["noisy_u8"], dev, **cfg)
+    diff = np.abs(pred.astype(int) - g[tag].astype(int))
+    print(f"demo {tag}: {int((diff > 0).sum())}/{diff.size} u8 values differ (max {diff.max()})")
+    assert pred.shape == (256, 256, 1) and diff.max() <= 1 and (diff > 0).mean() < 0.01
+
+
 def test_get_model_prediction_surface(dev):
     """Same call as scripts/tests.py:391: returns (uint8 HWC, ms)."""
     model = restormer.Restormer(LayerNorm_type="BiasFree").load_synthetic(42).eval().to(dev)
