@@ -387,6 +387,15 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
         else { if (st) irm_wait_vmcnt<NST>(); else irm_wait_vmcnt<0>(); }
         ++since_epi;
         asm volatile("s_barrier" ::: "memory");
+        // operands of the first k-step before anything else: their LDS round trip runs under the address
+        // math of the DMA issue instead of in front of the first MFMA
+        const float* xb = smem + (it % NS) * STG;
+        const float* wb = xb + XS;
+        float x0[PT], b0[CT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) x0[p] = xb[g * BN + wave * 16 * PT + p * 16 + r];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) b0[c] = wb[c * 4 * 64 + lane];
         if (it + NS - 1 < TOT) issue(it + NS - 1);
         if (s == 0) {
             const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
@@ -405,8 +414,6 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
             }
         }
 
-        const float* xb = smem + (it % NS) * STG;
-        const float* wb = xb + XS;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             float af[PT], bf[CT];
@@ -417,13 +424,13 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
             }
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
-                const float x = xb[(kk * 4 + g) * BN + wave * 16 * PT + p * 16 + r];
+                const float x = kk == 0 ? x0[p] : xb[(kk * 4 + g) * BN + wave * 16 * PT + p * 16 + r];
                 if (LN == IRM_LN_WITHBIAS) af[p] = fmaf(fmaf(x, rs[p], nmr[p]), wk, bk);
                 else if (LN == IRM_LN_BIASFREE) af[p] = x * rs[p] * wk;
                 else af[p] = x;
             }
 #pragma unroll
-            for (int c = 0; c < CT; ++c) bf[c] = wb[(c * 4 + kk) * 64 + lane];
+            for (int c = 0; c < CT; ++c) bf[c] = kk == 0 ? b0[c] : wb[(c * 4 + kk) * 64 + lane];
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
