@@ -454,7 +454,7 @@ def gen_deblurgan(ref, manifest):
 
 
 def gen_fullsize(ref, manifest):
-    """BASELINE.json configs[1] at its full tile size: the reference Restormer (motion-deblur configuration,
+    """BASELINE.json configs[3] (the headline workload) at its full tile size: the reference Restormer (motion-deblur configuration,
     synthetic weights seed 42) on tile 0 (512x512) of the benchmark's first synthetic 1280x720 frame.  The
     fixture keeps every 8th output pixel (49 KB) plus whole-tile moments."""
     from irm_amd.restormer import restormer as prod

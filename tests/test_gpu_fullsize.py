@@ -1,4 +1,4 @@
-"""Checks at BASELINE.json's full sizes (configs[1]: Restormer motion-deblur on 1280x720 frames, six
+"""Checks at BASELINE.json's full sizes (configs[3]: Restormer motion-deblur on 1280x720 frames, six
 512x512 tiles with overlap 96).
 
 The CPU oracle needs ~1 minute per 512x512 tile on a many-core host, so at this size the tests use
