@@ -24,6 +24,7 @@ SIGNATURES = {
     "irm_version": [],
     "irm_ln_stats_f32": [_P, _L, _P, _I, _I, _I, _F, _P],
     "irm_gemm1x1_f32": [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P],
+    "irm_gemm1x1_f16x3_f32": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P],
     "irm_dwconv3x3_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
     "irm_dwconv3x3_gate_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "irm_dwgemm_f32": [_P, _L, _P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _F, _P],
@@ -101,6 +102,23 @@ def pack_gemm_weight(w: torch.Tensor) -> torch.Tensor:
     wpad[:m, :k] = w
     # [mt][16 r][ks][4 g] -> [mt][ks][g][r]  (lane = g*16 + r)
     return wpad.view(mt, 16, ks, 4).permute(0, 2, 3, 1).contiguous().view(-1)
+
+
+def pack_gemm_weight_split(w: torch.Tensor) -> torch.Tensor:
+    """W [M][K] -> fp16 hi/lo parts in irm_gemm1x1_f16x3_f32's order (same number of floats as pack_gemm_weight):
+    [mtile][stage][hi|lo][lane = g*16 + m][j] = part[16 mtile + m][16 stage + 4 j + g]."""
+    w = w.detach().reshape(w.shape[0], -1).float()
+    m, k = w.shape
+    mt, st = (m + 15) // 16, (k + 15) // 16
+    wpad = torch.zeros(mt * 16, st * 16, dtype=torch.float32, device=w.device)
+    wpad[:m, :k] = w
+    hi = wpad.half()
+    lo = (wpad - hi.float()).half()
+
+    def arrange(t):                                   # [mt][16 m][st][4 j][4 g] -> [mt][st][g][m][j]
+        return t.view(mt, 16, st, 4, 4).permute(0, 2, 4, 1, 3)
+    packed = torch.stack([arrange(hi), arrange(lo)], dim=2).contiguous()      # [mt][st][2][g][m][j]
+    return packed.view(-1).view(torch.float32)
 
 
 def pack_conv3x3_weight(w: torch.Tensor) -> torch.Tensor:

@@ -276,7 +276,13 @@ __device__ __forceinline__ void irm_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int PT, int CT, int NS, int LN, bool RES>
+// F16: the GEMM proper runs on the fp16 matrix cores as an fp32 emulation - both operands are split into
+// fp16 hi + lo parts (x = hi + lo exactly up to 2^-22 |x|; the weights are split on the host), three
+// 16x16x16 MFMAs (lo*hi, hi*lo, hi*hi) accumulate in fp32: 2^-21 relative per product instead of 2^-24, at
+// 24 instead of 128 matrix cycles per tile and 16 channels, and off the fp32 datapath the VALU needs.
+typedef _Float16 irm_h4 __attribute__((ext_vector_type(4)));
+
+template <int PT, int CT, int NS, int LN, bool RES, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
     constexpr int BN = 64 * PT, BK = 16;            // pixels per workgroup, channels per stage
     constexpr int RPU = 256 / BN;                   // X rows per 1 KiB DMA instruction (PT 2: 2, PT 4: 1)
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
 #pragma unroll
         for (int p = 0; p < PT; ++p) x0[p] = xb[g * BN + wave * 16 * PT + p * 16 + r];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) b0[c] = wb[c * 4 * 64 + lane];
+        for (int c = 0; c < CT; ++c) b0[c] = F16 ? 0.0f : wb[c * 4 * 64 + lane];
         if (it + NS - 1 < TOT) issue(it + NS - 1);
         if (s == 0) {
             const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
@@ -414,6 +420,47 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
             }
         }
 
+        if constexpr (F16) {
+            // stage layout of the weights: per tile 64 lanes x (4 hi halves | 4 lo halves); lane (g, m) holds
+            // W[m][16 s + 4 j + g], j = 0..3 - the same channel order in which lane (g, i) reads x below
+            irm_h4 ah[PT], al[PT];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                float xv[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const float x = kk == 0 ? x0[p] : xb[(kk * 4 + g) * BN + wave * 16 * PT + p * 16 + r];
+                    if (LN == IRM_LN_WITHBIAS)
+                        xv[kk] = fmaf(fmaf(x, rs[p], nmr[p]), lnp[s * BK + kk * 4 + g], lnp[KP + s * BK + kk * 4 + g]);
+                    else if (LN == IRM_LN_BIASFREE) xv[kk] = x * rs[p] * lnp[s * BK + kk * 4 + g];
+                    else xv[kk] = x;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    ah[p][kk] = (_Float16)xv[kk];
+                    al[p][kk] = (_Float16)(xv[kk] - (float)ah[p][kk]);
+                }
+            }
+            irm_h4 bh[CT], bl[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                bh[c] = *reinterpret_cast<const irm_h4*>(wb + c * 256 + lane * 2);
+                bl[c] = *reinterpret_cast<const irm_h4*>(wb + c * 256 + 128 + lane * 2);
+            }
+            // three sweeps over the PT x CT independent accumulators (no MFMA waits on the one before it)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(al[p], bh[c], acc[p][c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[p], bl[c], acc[p][c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[p], bh[c], acc[p][c], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             float af[PT], bf[CT];
@@ -437,6 +484,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
                 for (int p = 0; p < PT; ++p) acc[p][c] = irm_mfma16(af[p], bf[c], acc[p][c]);
         }
 
+        }
         if (++s == S) {
             // pass finished: (+ bias, activation, + residual) and store tiles mt0 .. mt0 + CT - 1
             const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
@@ -486,20 +534,20 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
     }
 }
 
-template <int PT, int CT, int LN, bool RES>
+template <int PT, int CT, int LN, bool RES, bool F16 = false>
 static int launch_ring(const GemmArgs& a, int B, int ygroups, hipStream_t stream) {
     constexpr int NS = PT == 2 ? 4 : 3;
     constexpr int BN = 64 * PT;
     const size_t lds = ((size_t)NS * (16 * BN + CT * 256) + 2 * (size_t)a.ksteps * 4) * sizeof(float);
     static bool configured = false;              // per instantiation
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<PT, CT, NS, LN, RES>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<PT, CT, NS, LN, RES, F16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return IRM_ELAUNCH;
         configured = true;
     }
     dim3 grid((a.N + BN - 1) / BN, ygroups, B);
-    hipLaunchKernelGGL((gemm_ring_kernel<PT, CT, NS, LN, RES>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((gemm_ring_kernel<PT, CT, NS, LN, RES, F16>), grid, dim3(256), lds, stream, a);
     return irm_launch_status();
 }
 
@@ -522,6 +570,20 @@ static int launch_ring_any(const GemmArgs& a, int B, int ygroups, int pt, hipStr
     return launch_ring<2, CT, IRM_LN_NONE, false>(a, B, ygroups, stream);
 }
 
+// split-fp16 variant: 64-pixel waves, no residual
+template <int CT>
+static int launch_ring_split(const GemmArgs& a, int B, int ygroups, hipStream_t stream) {
+    static const int pt = [] { const char* e = getenv("IRM_GEMM_SPLIT_PT"); return e ? atoi(e) : 4; }();
+    if (pt == 2) {
+        if (a.ln_mode == IRM_LN_WITHBIAS) return launch_ring<2, CT, IRM_LN_WITHBIAS, false, true>(a, B, ygroups, stream);
+        if (a.ln_mode == IRM_LN_BIASFREE) return launch_ring<2, CT, IRM_LN_BIASFREE, false, true>(a, B, ygroups, stream);
+        return launch_ring<2, CT, IRM_LN_NONE, false, true>(a, B, ygroups, stream);
+    }
+    if (a.ln_mode == IRM_LN_WITHBIAS) return launch_ring<4, CT, IRM_LN_WITHBIAS, false, true>(a, B, ygroups, stream);
+    if (a.ln_mode == IRM_LN_BIASFREE) return launch_ring<4, CT, IRM_LN_BIASFREE, false, true>(a, B, ygroups, stream);
+    return launch_ring<4, CT, IRM_LN_NONE, false, true>(a, B, ygroups, stream);
+}
+
 template <int PT, int CT>
 static int launch_gemm(const GemmArgs& a, int B, int ygroups, bool vec, hipStream_t stream) {
     constexpr int BN = 64 * PT;
@@ -537,11 +599,16 @@ static bool irm_force_generic() {
     static const bool v = getenv("IRM_GEMM_GENERIC") != nullptr;   // A/B switch for benchmarking only
     return v;
 }
-extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long x_bs, float* y, long y_bs,
-                               const float* res, long r_bs, const float* bias, const float* stats,
-                               const float* lnw, const float* lnb, int ln_mode, int act, int B, int M, int K,
-                               int N, int ct, int ygroups, float* stats_out, float eps, const float* res_scale,
-                               hipStream_t stream) {
+// gemm_xres.hip: input-resident variant of the emulated GEMM for K <= 96
+int irm_gemm_xres_dispatch(const float* wp, const float* x, long x_bs, float* y, long y_bs, const float* bias,
+                           const float* stats, const float* lnw, const float* lnb, int ln_mode, int act, int B, int M,
+                           int K, int N, hipStream_t stream);
+
+static int gemm_entry(const float* wp, long w_bs, const float* x, long x_bs, float* y, long y_bs,
+                      const float* res, long r_bs, const float* bias, const float* stats,
+                      const float* lnw, const float* lnb, int ln_mode, int act, int B, int M, int K,
+                      int N, int ct, int ygroups, float* stats_out, float eps, const float* res_scale,
+                      bool split, hipStream_t stream) {
     if (!wp || !x || !y || B <= 0 || M <= 0 || K <= 0 || N <= 0) return IRM_EINVAL;
     if (ln_mode != IRM_LN_NONE && (!stats || !lnw || (ln_mode == IRM_LN_WITHBIAS && !lnb))) return IRM_EINVAL;
     if (ln_mode < 0 || ln_mode > 2 || act < 0 || act > 3) return IRM_EINVAL;
@@ -561,6 +628,23 @@ extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long 
     if (ygroups <= 0) ygroups = 1;
     if (ygroups > nchunks) ygroups = nchunks;
     if (B > 65535 || ygroups > 65535) return IRM_EINVAL;
+    if (split) {
+        // weights packed by the caller as fp16 hi/lo pairs: only the ring kernel understands them
+        if (!vec || N < 4 || res || w_bs) return IRM_EINVAL;
+        static const bool no_xres = getenv("IRM_GEMM_NO_XRES") != nullptr;
+        if (K <= 96 && !stats_out && !no_xres && B <= 65535 && (long)(N + 127) / 128 <= 2147483647L) {
+            const int rc = irm_gemm_xres_dispatch(wp, x, x_bs, y, y_bs, bias, stats, lnw, lnb, ln_mode, act, B, M, K, N, stream);
+            if (rc != IRM_EINVAL) return rc;
+        }
+        switch (ct) {
+            case 3: return launch_ring_split<3>(a, B, ygroups, stream);
+            case 4: return launch_ring_split<4>(a, B, ygroups, stream);
+            case 6: return launch_ring_split<6>(a, B, ygroups, stream);
+            case 8: return launch_ring_split<8>(a, B, ygroups, stream);
+            case 9: return launch_ring_split<9>(a, B, ygroups, stream);
+            default: return IRM_EINVAL;
+        }
+    }
     if (vec && N >= 4 && !irm_force_generic() && !(res && ln_mode != IRM_LN_NONE)) {
         // 64 pixels per wave (PT 4) doubles the MFMAs per barrier; it is used when the accumulators
         // (+ the prefetched residual) still fit 2 waves per SIMD and the grid stays large
@@ -583,4 +667,21 @@ extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long 
         case 9: return launch_gemm<2, 9>(a, B, ygroups, vec, stream);
         default: return IRM_EINVAL;
     }
+}
+
+extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long x_bs, float* y, long y_bs,
+                               const float* res, long r_bs, const float* bias, const float* stats,
+                               const float* lnw, const float* lnb, int ln_mode, int act, int B, int M, int K,
+                               int N, int ct, int ygroups, float* stats_out, float eps, const float* res_scale,
+                               hipStream_t stream) {
+    return gemm_entry(wp, w_bs, x, x_bs, y, y_bs, res, r_bs, bias, stats, lnw, lnb, ln_mode, act, B, M, K, N, ct,
+                      ygroups, stats_out, eps, res_scale, false, stream);
+}
+
+extern "C" int irm_gemm1x1_f16x3_f32(const float* wp_split, const float* x, long x_bs, float* y, long y_bs,
+                                     const float* bias, const float* stats, const float* lnw, const float* lnb,
+                                     int ln_mode, int act, int B, int M, int K, int N, int ct, int ygroups,
+                                     float* stats_out, float eps, hipStream_t stream) {
+    return gemm_entry(wp_split, 0, x, x_bs, y, y_bs, nullptr, 0, bias, stats, lnw, lnb, ln_mode, act, B, M, K, N, ct,
+                      ygroups, stats_out, eps, nullptr, true, stream);
 }

@@ -88,7 +88,7 @@ def ln_stats(x: torch.Tensor, stats: torch.Tensor, eps: float = 1e-5):
 
 def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, *, res=None, bias=None,
             stats=None, lnw=None, lnb=None, ln_mode=LN_NONE, act=ACT_NONE, w_bs: int = 0, ct: int | None = None,
-            ygroups: int | None = None, stats_out=None, eps: float = 1e-5, res_scale=None):
+            ygroups: int | None = None, stats_out=None, eps: float = 1e-5, res_scale=None, split: bool = False):
     """y = act(W @ LN(x) + bias) (+ res); wp from _hip.pack_gemm_weight.
     stats_out: optional [B,2,N] buffer receiving the LayerNorm statistics of y (needs M <= 16*ct)."""
     _chk(x, "x"), _chk(y, "y")
@@ -109,6 +109,14 @@ def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, 
         ygroups = 1
     nbytes = 4.0 * B * N * (K + M + (M if res is not None else 0) + (2 if stats is not None else 0)
                             + (2 if stats_out is not None else 0))
+    if split:
+        # wp from _hip.pack_gemm_weight_split: fp32 emulation on the fp16 matrix cores (no residual)
+        assert res is None and w_bs == 0 and res_scale is None
+        _launch("gemm1x1_f16x3", 2.0 * B * M * K * N, nbytes, "irm_gemm1x1_f16x3_f32", _hip.ptr(wp), _hip.ptr(x), _bs(x),
+                _hip.ptr(y), _bs(y), _hip.ptr(bias), _hip.ptr(stats), _hip.ptr(lnw), _hip.ptr(lnb), int(ln_mode),
+                int(act), B, M, K, N, ct, ygroups, _hip.ptr(stats_out), float(eps),
+                tag=f"M{M} K{K} N{N} B{B} ln{int(ln_mode)} ct{ct} yg{ygroups}")
+        return
     _launch("gemm1x1", 2.0 * B * M * K * N, nbytes, "irm_gemm1x1_f32", _hip.ptr(wp), int(w_bs), _hip.ptr(x), _bs(x),
             _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), _hip.ptr(stats), _hip.ptr(lnw),
             _hip.ptr(lnb), int(ln_mode), int(act), B, M, K, N, ct, ygroups, _hip.ptr(stats_out), float(eps),

@@ -138,6 +138,7 @@ class Restormer(nn.Module):
         self.output = nn.Conv2d(d2, out_channels, 3, padding=1, bias=bias)
         self._packed = None
         self._packed_key = None
+        self._split = False
         self._ws_by_stream = {}
         #: tiles of one image processed per forward by the device tiler (utils.tiled_forward_device)
         self.max_tiles_per_batch = 9
@@ -168,6 +169,12 @@ class Restormer(nn.Module):
         def f32(t):
             return None if t is None else t.detach().float().contiguous()
 
+        # the two LayerNorm-prologue GEMMs of a block (qkv, project_in: 2/3 of the GEMM FLOPs) run as an fp32
+        # emulation on the fp16 matrix cores (irm_gemm1x1_f16x3_f32; its error against float64 is not larger
+        # than the exact-fp32 kernel's, and a LayerNorm output cannot leave the fp16 range): weights split into
+        # fp16 hi/lo here.  IRM_GEMM_EXACT=1 keeps every GEMM on the f32-input MFMA.
+        self._split = not os.environ.get("IRM_GEMM_EXACT")
+
         for name, m in self.named_modules():
             if isinstance(m, TransformerBlock):
                 a, ff = m.attn, m.ffn
@@ -180,6 +187,9 @@ class Restormer(nn.Module):
                     ffn_dw=f32(ff.dwconv.weight.reshape(-1, 9)), ffn_dw_b=f32(ff.dwconv.bias),
                     pout=_hip.pack_gemm_weight(ff.project_out.weight), pout_b=f32(ff.project_out.bias),
                     n1w=f32(m.norm1.w), n1b=f32(m.norm1.b), n2w=f32(m.norm2.w), n2b=f32(m.norm2.b))
+                if self._split:
+                    pk[name].update(qkv_s=_hip.pack_gemm_weight_split(a.qkv.weight),
+                                    pin_s=_hip.pack_gemm_weight_split(ff.project_in.weight))
                 if ops.can_fuse_dw(m.dim, 4):
                     # depth-wise coefficient tables of the fused dw + 1x1 kernel (irm_dwgemm_f32)
                     c, dw, dwb = m.dim, a.qkv_dwconv.weight.reshape(-1, 9), a.qkv_dwconv.bias
@@ -238,8 +248,9 @@ class Restormer(nn.Module):
         # --- attention branch: x += project_out(softmax(q k^T) v)   (restormer.py:111-132, 147)
         if not have_stats:
             ops.ln_stats(x, stats)
-        ops.gemm1x1(w["qkv"], x, qkv, 3 * C, C, bias=w["qkv_b"], stats=stats, lnw=w["n1w"], lnb=w["n1b"],
-                    ln_mode=blk.norm1.mode)
+        split = self._split and N % 4 == 0            # the emulation kernel needs the 16-byte fast path
+        ops.gemm1x1(w["qkv_s" if split else "qkv"], x, qkv, 3 * C, C, bias=w["qkv_b"], stats=stats, lnw=w["n1w"],
+                    lnb=w["n1b"], ln_mode=blk.norm1.mode, split=split)
         fuse_dw = "v_dwp" in w and ops.can_fuse_dw(C, W) and not os.environ.get("IRM_NO_FUSE_DW")
         if fuse_dw:
             # q, k only: the depth-wise conv of v happens inside the apply GEMM below
@@ -268,8 +279,8 @@ class Restormer(nn.Module):
         g = big_b[:B * hid * N].view(B, hid, H, W)
         if not fuse:
             ops.ln_stats(x, stats)
-        ops.gemm1x1(w["pin"], x, h, 2 * hid, C, bias=w["pin_b"], stats=stats, lnw=w["n2w"], lnb=w["n2b"],
-                    ln_mode=blk.norm2.mode)
+        ops.gemm1x1(w["pin_s" if split else "pin"], x, h, 2 * hid, C, bias=w["pin_b"], stats=stats, lnw=w["n2w"],
+                    lnb=w["n2b"], ln_mode=blk.norm2.mode, split=split)
         emit = fuse and want_stats
         if fuse_dw:
             ops.dwgemm(w["pout"], w["ffn_dwp"], h, x, C, hid, gate=True, res=x, bias=w["pout_b"],

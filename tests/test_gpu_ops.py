@@ -173,6 +173,44 @@ def test_dwconv3x3_gate(dev, B, hid, H, W):
     assert (y.cpu().double() - ref).abs().max() < TOL
 
 
+@pytest.mark.parametrize("M,K,H,W,B,ln,bias,ct", [(144, 48, 16, 24, 2, 1, False, 9), (510, 96, 16, 32, 1, 2, True, 8),
+                                                  (254, 48, 8, 32, 2, 1, False, 8), (96, 255, 16, 16, 1, 0, True, 6),
+                                                  (1020, 192, 8, 16, 2, 1, False, 8)])
+def test_gemm1x1_f16x3(dev, M, K, H, W, B, ln, bias, ct):
+    """fp32 emulation on the fp16 matrix cores (hi/lo split, three MFMAs): against float64 and against the
+    exact-fp32 kernel - the emulation must stay at fp32 rounding level (2^-21 per product)."""
+    N = H * W
+    x = rnd(f"sx{M}{K}", (B, K, H, W), -2, 3)
+    w = rnd(f"sw{M}{K}", (M, K), -0.3, 0.3)
+    lnw, lnb = rnd(f"slw{K}", (K,), 0.5, 1.5), rnd(f"slb{K}", (K,), -0.2, 0.2)
+    bv = rnd(f"sb{M}", (M,), -0.3, 0.3) if bias else None
+    xd = x.double()
+    if ln:
+        mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+        xn = (xd - mu) / torch.sqrt(var + 1e-5) * lnw.double().view(1, K, 1, 1) if ln == 1 else \
+            xd / torch.sqrt(var + 1e-5) * lnw.double().view(1, K, 1, 1)
+        if ln == 1:
+            xn = xn + lnb.double().view(1, K, 1, 1)
+    else:
+        xn = xd
+    ref = torch.einsum("mk,bkhw->bmhw", w.double(), xn)
+    if bias:
+        ref = ref + bv.double().view(1, M, 1, 1)
+    xg = x.to(dev)
+    st = torch.empty(B, 2, N, device=dev)
+    if ln:
+        ops.ln_stats(xg, st)
+    kw = dict(bias=bv.to(dev) if bias else None, stats=st if ln else None, lnw=lnw.to(dev) if ln else None,
+              lnb=lnb.to(dev) if ln == 1 else None, ln_mode=ln, ct=ct)
+    y16, y32 = torch.empty(B, M, H, W, device=dev), torch.empty(B, M, H, W, device=dev)
+    ops.gemm1x1(_hip.pack_gemm_weight_split(w).to(dev), xg, y16, M, K, split=True, **kw)
+    ops.gemm1x1(_hip.pack_gemm_weight(w).to(dev), xg, y32, M, K, **kw)
+    e16 = (y16.cpu().double() - ref).abs().max().item()
+    e32 = (y32.cpu().double() - ref).abs().max().item()
+    print(f"M{M} K{K}: max-abs vs float64  f16x3 {e16:.3e}   f32 {e32:.3e}")
+    assert e16 < 2e-5 and e16 < 8 * max(e32, 1e-7)
+
+
 DWGEMM_CASES = [
     # M, K, H, W, B, gate, res, bias, stats, per_batch
     (48, 127, 19, 36, 2, True, True, False, True, False),
