@@ -80,8 +80,8 @@ def cpu_baseline(model, frame_u8, gpu_tile, tile_edge):
 
 #: timer group -> (kernel label, roofline that bounds it, regex of its instantiations in the PMC table)
 ROOFLINE_KERNELS = {
-    "gemm1x1_f16x3": ("gemm_ring_kernel<F16> (irm_gemm1x1_f16x3_f32: LayerNorm + 1x1 conv, fp32 emulated by three fp16 "
-                      "MFMAs, fp32 accumulate)", "hbm", r"^gemm_ring_kernel<.*, true>$"),
+    "gemm1x1_f16x3": ("gemm_xres_kernel / gemm_ring_kernel<F16> (irm_gemm1x1_f16x3_f32: LayerNorm + 1x1 conv, fp32 emulated "
+                      "by three fp16 MFMAs, fp32 accumulate)", "hbm", r"^(gemm_ring_kernel<.*, true>|gemm_xres_kernel)"),
     "gemm1x1": ("gemm_ring_kernel (irm_gemm1x1_f32, exact f32 MFMA)", "mfma", r"^gemm_(ring_kernel<.*, false>|pw_kernel.*)$"),
     "dwgemm": ("dwgemm_kernel (irm_dwgemm_f32)", "mfma", r"^dwgemm_kernel"),
     "conv3x3": ("conv3x3_ring_kernel (irm_conv3x3_f32)", "mfma", r"^conv3x3_"),
