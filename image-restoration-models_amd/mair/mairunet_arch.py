@@ -20,6 +20,8 @@ from __future__ import annotations
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -127,7 +129,11 @@ def pack_block(m: VSSBlock) -> dict:
         return None if t is None else t.detach().float().contiguous()
     a = m.self_attention
     D = a.d_inner
+    # the two LayerNorm-prologue GEMMs (in_proj, fc1) also in the hi/lo fp16 order of irm_gemm1x1_f16x3_f32
+    split = {} if os.environ.get("IRM_GEMM_EXACT") else dict(
+        inp_s=_hip.pack_gemm_weight_split(a.in_proj.weight), fc1_s=_hip.pack_gemm_weight_split(m.ffn.fc1.weight))
     return dict(
+        **split,
         inp=_hip.pack_gemm_weight(a.in_proj.weight), inp_b=f32(a.in_proj.bias),
         dw=f32(a.conv2d.weight.reshape(D, 9)), dw_b=f32(a.conv2d.bias),
         xproj=_hip.pack_gemm_weight(a.x_proj_weight.reshape(-1, D)),
@@ -191,8 +197,9 @@ class MambaHost(nn.Module):
         # --- x = x * skip_scale + LoSh2D(LN(x))     (mairunet_arch.py:263-282, 374-375)
         if not have_stats:
             ops.ln_stats(x, stats)
-        ops.gemm1x1(w["inp"], x, xz, 2 * D, C, bias=w["inp_b"], stats=stats, lnw=w["ln1w"], lnb=w["ln1b"],
-                    ln_mode=ops.LN_WITHBIAS)
+        split = "inp_s" in w and L % 4 == 0           # fp32 emulation on the fp16 matrix cores (needs the 16-byte path)
+        ops.gemm1x1(w["inp_s" if split else "inp"], x, xz, 2 * D, C, bias=w["inp_b"], stats=stats, lnw=w["ln1w"],
+                    lnb=w["ln1b"], ln_mode=ops.LN_WITHBIAS, split=split)
         ops.dwconv3x3(xz[:, :D], w["dw"], xc, bias=w["dw_b"], act=ops.ACT_SILU)
         ops.gemm1x1(w["xproj"], xc, proj, 4 * J, D)
         ops.transpose(xc.view(B, D, L), xT, D, L)
@@ -206,8 +213,8 @@ class MambaHost(nn.Module):
         h = self._buf("mlp_h", B * hid * L, dev).view(B, hid, H, W)
         if not fuse:
             ops.ln_stats(x, stats)
-        ops.gemm1x1(w["fc1"], x, h, hid, C, bias=w["fc1_b"], stats=stats, lnw=w["ln2w"], lnb=w["ln2b"],
-                    ln_mode=ops.LN_WITHBIAS, act=ops.ACT_GELU)
+        ops.gemm1x1(w["fc1_s" if split else "fc1"], x, h, hid, C, bias=w["fc1_b"], stats=stats, lnw=w["ln2w"],
+                    lnb=w["ln2b"], ln_mode=ops.LN_WITHBIAS, act=ops.ACT_GELU, split=split)
         emit = fuse and want_stats
         ops.gemm1x1(w["fc2"], h, x, C, hid, res=x, bias=w["fc2_b"], res_scale=w["s2"],
                     stats_out=stats if emit else None)
