@@ -132,17 +132,28 @@ __device__ __forceinline__ v2f dg_gelu2(v2f x) {
 
 // PT = pixels per lane: 4 -> 4 waves, each a 4 x 16 patch; 2 -> 8 waves, each a 2 x 16 patch (half the
 // accumulators per wave: <= 128 VGPRs, 16 waves per CU, for the 96-channel outputs)
-template <int CT, bool GATE, int NS, int PT>
+// F16: the 1x1 part as an fp32 emulation on the fp16 matrix cores.  The lane's stencil outputs of 4 consecutive
+// stages (channels 16G + 4j + g, j = 0..3 - exactly the k-slots lane (g, i) owns in a 16x16x16 MFMA) are kept in
+// registers and split into fp16 hi + lo (scaled by 2^-4 so that gated activations up to 10^6 stay in range);
+// every 4th stage three MFMAs per tile (lo*hi, hi*lo, hi*hi) accumulate in fp32.  The split weights of a
+// 16-channel group (host packed: irm_gemm1x1_f16x3_f32's order) arrive in quarters with the 4 stages through one
+// extra, partly masked DMA instruction per wave and stage, into a double-buffered area next to the ring.
+typedef _Float16 dg_h4 __attribute__((ext_vector_type(4)));
+
+template <int CT, bool GATE, int NS, int PT, bool F16 = false>
 __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 2) void dwgemm_kernel(DwGemmArgs a) {
     constexpr int NT = PT == 4 ? 256 : 512;        // threads per workgroup
     constexpr int NP = GATE ? 8 : 4;               // halo planes per stage
     constexpr int DWS = GATE ? 40 : 20;            // depth-wise coefficients per channel (floats, each twice)
-    constexpr int XC = NP * 100, WC = CT * 16;     // 16-byte chunks per stage
+    constexpr int XC = NP * 100, WC = F16 ? 0 : CT * 16;   // 16-byte chunks per stage (F16: weights bypass the ring)
     constexpr int TC = XC + WC + DWS;
     constexpr int R = (TC + NT - 1) / NT;          // DMA instructions per lane per stage
     constexpr int STG = R * NT * 4;                // floats per stage
-    static_assert((NS - 2) * R <= 63, "vmcnt field");
+    constexpr int RW = R + (F16 ? 1 : 0);          // DMA instructions per wave and stage
+    static_assert((NS - 2) * RW <= 63, "vmcnt field");
+    static_assert(!F16 || (PT == 4 && CT * 4 <= 64), "F16 variant: 4 waves, one masked weight instruction each");
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* warea = smem + NS * STG;                // F16: [group parity][quarter][CT * 64] floats
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
@@ -157,6 +168,8 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
     const float* X = a.X + (long)b * a.x_bs;
     const float* Wp = a.Wp + (long)b * a.w_bs;
     const int S = (a.K + 3) >> 2;
+    const int SL = F16 ? ((S + 3) & ~3) : S;       // F16: whole 16-channel groups (stages beyond S carry zeros)
+    const int groups = a.ksteps >> 2;              // 16-channel groups of the packed weights
 
     // per-lane DMA sources: src(s) = s < lim ? base + s * stride : zero page
     const float* base[R];
@@ -191,10 +204,10 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
 
     // running source pointers (border / unused lanes: zero page, stride 0); only a ragged last stage
     // (K % 4 != 0) has to look at lim
-    const bool ragged = (a.K & 3) != 0;
+    const bool ragged = (a.K & 3) != 0 || SL != S;
     auto issue = [&](int s) {
         float* dst = smem + (s % NS) * STG + wave * 256;
-        const bool tail = ragged && s == S - 1;
+        const bool tail = ragged && s >= S - 1;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const float* src = (tail && s >= lim[j]) ? dg_zero_page : base[j];
@@ -202,11 +215,22 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
             if (!(a.dbg & 1)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + j * NT * 4), 16, 0, 0);
         }
+        if constexpr (F16) {
+            // quarter (s & 3) of the split weights of group s >> 2: CT*16 pieces of 16 bytes, CT*4 lanes per wave
+            if (lane < CT * 4) {
+                const int cq = wave * (CT * 4) + lane, ct = cq >> 4;
+                const float* src = ct < a.mtiles
+                    ? Wp + ((long)ct * groups + (s >> 2)) * 256 + (s & 3) * 64 + (cq & 15) * 4 : dg_zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                    (__attribute__((address_space(3))) void*)(warea + ((s >> 2) & 1) * (CT * 256) + (s & 3) * (CT * 64) +
+                                                              wave * (CT * 16)), 16, 0, 0);
+            }
+        }
     };
 
 #pragma unroll
     for (int j = 0; j < NS - 1; ++j)
-        if (j < S) issue(j);
+        if (j < SL) issue(j);
 
     // accumulators start from bias + residual: lane (g, i) holds channel 16c + i of the pixel quads q < PT,
     // row PT*(wave>>1) + q, columns 16*(wave&1) + 4*g + [0,4)
@@ -232,7 +256,8 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
                 rr = *reinterpret_cast<const float4*>(Rp + (ok ? (long)co * plane + pix[q] : 0));
                 if (!ok) rr = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            acc[q][c] = (f32x4){rr.x + bv, rr.y + bv, rr.z + bv, rr.w + bv};
+            constexpr float sc = F16 ? 0.0625f : 1.0f;     // F16 accumulates in units of 2^-4
+            acc[q][c] = (f32x4){(rr.x + bv) * sc, (rr.y + bv) * sc, (rr.z + bv) * sc, (rr.w + bv) * sc};
         }
     }
 
@@ -240,12 +265,13 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
     // PT x 16 patch); img_off = top-left tap of the first pixel in the halo image
     const int img_off = g * 400 + (wave >> 1) * (PT * 40) + 16 * (wave & 1) + i + 3;
 
-    for (int s = 0; s < S; ++s) {
-        const int rem = min(NS - 2, S - 1 - s);
-        if (rem >= NS - 2 && NS >= 3) dg_wait_vmcnt<(NS - 2) * R>();
+    float ag[4][PT];                               // F16: stencil outputs of the 4 stages of a group
+    for (int s = 0; s < SL; ++s) {
+        const int rem = min(NS - 2, SL - 1 - s);
+        if (rem >= NS - 2 && NS >= 3) dg_wait_vmcnt<(NS - 2) * RW>();
         else dg_wait_vmcnt<0>();
         asm volatile("s_barrier" ::: "memory");
-        if (s + NS - 1 < S) issue(s + NS - 1);
+        if (s + NS - 1 < SL) issue(s + NS - 1);
 
         if (a.dbg & 2) continue;
         const float* xb = smem + (s % NS) * STG;
@@ -268,22 +294,64 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
             #pragma unroll
             for (int h = 0; h < PT / 2; ++h) { af[2 * h] = oa[h].x; af[2 * h + 1] = oa[h].y; }
         }
-        // (the f32 MFMA shares the SIMD's fp32 datapath with the VALU: interleaving the two streams inside
-        // a wave or across waves buys nothing, the kernel costs VALU + MFMA time)
-        float bf[CT];
+        if constexpr (F16) {
+            // park this stage's outputs in slot s & 3 (uniform select: the loop is not unrolled by 4)
+            const int j4 = s & 3;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) bf[c] = wb[c * 64 + lane];
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
+                for (int p = 0; p < PT; ++p) ag[j][p] = j4 == j ? af[p] : (j4 < j ? 0.0f : ag[j][p]);
+            if (j4 == 3) {
+                dg_h4 ah[PT], al[PT];
 #pragma unroll
-            for (int p = 0; p < PT; ++p) acc[p][c] = irm_mfma16(af[p], bf[c], acc[p][c]);
+                for (int p = 0; p < PT; ++p)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float x = ag[j][p] * 0.0625f;
+                        ah[p][j] = (_Float16)x;
+                        al[p][j] = (_Float16)(x - (float)ah[p][j]);
+                    }
+                const float* wa = warea + ((s >> 2) & 1) * (CT * 256) + (lane >> 5) * (CT * 64) + (lane & 31) * 2;
+                dg_h4 bh[CT], bl[CT];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    bh[c] = *reinterpret_cast<const dg_h4*>(wa + c * 64);
+                    bl[c] = *reinterpret_cast<const dg_h4*>(wa + 2 * (CT * 64) + c * 64);
+                }
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(al[p], bh[c], acc[p][c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[p], bl[c], acc[p][c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[p], bh[c], acc[p][c], 0, 0, 0);
+            }
+        } else {
+            // (the f32 MFMA shares the SIMD's fp32 datapath with the VALU: interleaving the two streams inside
+            // a wave or across waves buys nothing, the kernel costs VALU + MFMA time)
+            float bf[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) bf[c] = wb[c * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc[p][c] = irm_mfma16(af[p], bf[c], acc[p][c]);
+        }
     }
 
     float4 t[PT][CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int q = 0; q < PT; ++q) t[q][c] = make_float4(acc[q][c][0], acc[q][c][1], acc[q][c][2], acc[q][c][3]);
+        for (int q = 0; q < PT; ++q) {
+            constexpr float sc = F16 ? 16.0f : 1.0f;
+            t[q][c] = make_float4(acc[q][c][0] * sc, acc[q][c][1] * sc, acc[q][c][2] * sc, acc[q][c][3] * sc);
+        }
     if (a.stats_out) dg_stats<CT, PT>(t, a.M, plane, i, pix, a.stats_out + (long)b * 2 * plane, a.eps);
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -295,28 +363,28 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
     }
 }
 
-template <int CT, bool GATE, int PT>
+template <int CT, bool GATE, int PT, bool F16 = false>
 static int dg_launch(const DwGemmArgs& a, int B, hipStream_t stream) {
     constexpr int NS = 3;                          // deeper rings (4..6) measured no faster: occupancy matters more
     constexpr int NT = PT == 4 ? 256 : 512;
-    constexpr int TC = (GATE ? 800 : 400) + CT * 16 + (GATE ? 40 : 20);
+    constexpr int TC = (GATE ? 800 : 400) + (F16 ? 0 : CT * 16) + (GATE ? 40 : 20);
     constexpr int R = (TC + NT - 1) / NT;
-    const size_t lds = (size_t)NS * R * NT * 16;
+    const size_t lds = (size_t)NS * R * NT * 16 + (F16 ? 2 * CT * 1024 : 0);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgemm_kernel<CT, GATE, NS, PT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgemm_kernel<CT, GATE, NS, PT, F16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return IRM_ELAUNCH;
         configured = true;
     }
     const int per = (a.tiles + 7) >> 3;
-    hipLaunchKernelGGL((dwgemm_kernel<CT, GATE, NS, PT>), dim3(per * 8, B), dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL((dwgemm_kernel<CT, GATE, NS, PT, F16>), dim3(per * 8, B), dim3(NT), lds, stream, a);
     return irm_launch_status();
 }
 
-extern "C" int irm_dwgemm_f32(const float* wp, long w_bs, const float* dwp, const float* x, long x_bs, float* y,
-                              long y_bs, const float* res, long r_bs, const float* bias, int gate, int B, int M,
-                              int K, int H, int W, float* stats_out, float eps, hipStream_t stream) {
+static int dwgemm_entry(const float* wp, long w_bs, const float* dwp, const float* x, long x_bs, float* y,
+                        long y_bs, const float* res, long r_bs, const float* bias, int gate, int B, int M,
+                        int K, int H, int W, float* stats_out, float eps, bool split, hipStream_t stream) {
     if (!wp || !dwp || !x || !y || B <= 0 || M <= 0 || K <= 0 || H <= 0 || W <= 0) return IRM_EINVAL;
     if (M > 96 || (W & 3) || B > 65535) return IRM_EINVAL;
     if ((x_bs & 3) || (y_bs & 3) || (r_bs & 3) || (w_bs & 3) || !irm_aligned16(x) || !irm_aligned16(y) ||
@@ -330,6 +398,11 @@ extern "C" int irm_dwgemm_f32(const float* wp, long w_bs, const float* dwp, cons
     a.tiles_x = (W + 31) / 32;
     a.tiles = a.tiles_x * ((H + 7) / 8);
     { const char* e = getenv("IRM_DWGEMM_DBG"); a.dbg = e ? atoi(e) : 0; }
+    if (split) {
+        if (w_bs) return IRM_EINVAL;               // the split weights come from the host: shared by all samples
+        if (a.mtiles <= 3) return gate ? dg_launch<3, true, 4, true>(a, B, stream) : dg_launch<3, false, 4, true>(a, B, stream);
+        return gate ? dg_launch<6, true, 4, true>(a, B, stream) : dg_launch<6, false, 4, true>(a, B, stream);
+    }
     static const int pt_env = [] { const char* e = getenv("IRM_DWGEMM_PT"); return e ? atoi(e) : 0; }();
     const int pt = pt_env == 2 ? 2 : 4;      // 8 waves x 2 pixels: twice the occupancy, measured no faster
     if (a.mtiles <= 3) {
@@ -338,4 +411,18 @@ extern "C" int irm_dwgemm_f32(const float* wp, long w_bs, const float* dwp, cons
     }
     if (pt == 4) return gate ? dg_launch<6, true, 4>(a, B, stream) : dg_launch<6, false, 4>(a, B, stream);
     return gate ? dg_launch<6, true, 2>(a, B, stream) : dg_launch<6, false, 2>(a, B, stream);
+}
+
+extern "C" int irm_dwgemm_f32(const float* wp, long w_bs, const float* dwp, const float* x, long x_bs, float* y,
+                              long y_bs, const float* res, long r_bs, const float* bias, int gate, int B, int M,
+                              int K, int H, int W, float* stats_out, float eps, hipStream_t stream) {
+    return dwgemm_entry(wp, w_bs, dwp, x, x_bs, y, y_bs, res, r_bs, bias, gate, B, M, K, H, W, stats_out, eps, false,
+                        stream);
+}
+
+extern "C" int irm_dwgemm_f16x3_f32(const float* wp_split, const float* dwp, const float* x, long x_bs, float* y,
+                                    long y_bs, const float* res, long r_bs, const float* bias, int gate, int B, int M,
+                                    int K, int H, int W, float* stats_out, float eps, hipStream_t stream) {
+    return dwgemm_entry(wp_split, 0, dwp, x, x_bs, y, y_bs, res, r_bs, bias, gate, B, M, K, H, W, stats_out, eps, true,
+                        stream);
 }

@@ -146,7 +146,7 @@ def can_fuse_dw(M: int, W: int) -> bool:
 
 
 def dwgemm(wp, dwp, x, y, M: int, K: int, *, gate: bool, res=None, bias=None, w_bs: int = 0, stats_out=None,
-           eps: float = 1e-5):
+           eps: float = 1e-5, split: bool = False):
     """y = W @ g + bias (+ res), g = gelu(dw(x[:, :K])) * dw(x[:, K:2K]) (gate) or dw(x[:, :K]);
     dwp from _hip.pack_dw_table."""
     _chk(x, "x"), _chk(y, "y")
@@ -158,6 +158,13 @@ def dwgemm(wp, dwp, x, y, M: int, K: int, *, gate: bool, res=None, bias=None, w_
     nbytes = 4.0 * B * N * ((2 * K if gate else K) + M + (M if res is not None else 0)
                             + (2 if stats_out is not None else 0))
     flops = B * N * (2.0 * M * K + (36.0 if gate else 18.0) * K)
+    if split:
+        # wp from _hip.pack_gemm_weight_split: the 1x1 part as an fp32 emulation on the fp16 matrix cores
+        assert w_bs == 0
+        _launch("dwgemm_f16x3", flops, nbytes, "irm_dwgemm_f16x3_f32", _hip.ptr(wp), _hip.ptr(dwp), _hip.ptr(x), _bs(x),
+                _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), int(bool(gate)), B, M, K, H, W,
+                _hip.ptr(stats_out), float(eps), tag=f"M{M} K{K} {H}x{W} B{B} gate{int(bool(gate))}")
+        return
     _launch("dwgemm", flops, nbytes, "irm_dwgemm_f32", _hip.ptr(wp), int(w_bs), _hip.ptr(dwp), _hip.ptr(x), _bs(x),
             _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), int(bool(gate)), B, M, K, H, W,
             _hip.ptr(stats_out), float(eps), tag=f"M{M} K{K} {H}x{W} B{B} gate{int(bool(gate))}")

@@ -189,7 +189,8 @@ class Restormer(nn.Module):
                     n1w=f32(m.norm1.w), n1b=f32(m.norm1.b), n2w=f32(m.norm2.w), n2b=f32(m.norm2.b))
                 if self._split:
                     pk[name].update(qkv_s=_hip.pack_gemm_weight_split(a.qkv.weight),
-                                    pin_s=_hip.pack_gemm_weight_split(ff.project_in.weight))
+                                    pin_s=_hip.pack_gemm_weight_split(ff.project_in.weight),
+                                    pout_s=_hip.pack_gemm_weight_split(ff.project_out.weight))
                 if ops.can_fuse_dw(m.dim, 4):
                     # depth-wise coefficient tables of the fused dw + 1x1 kernel (irm_dwgemm_f32)
                     c, dw, dwb = m.dim, a.qkv_dwconv.weight.reshape(-1, 9), a.qkv_dwconv.bias
@@ -283,8 +284,8 @@ class Restormer(nn.Module):
                     lnb=w["n2b"], ln_mode=blk.norm2.mode, split=split)
         emit = fuse and want_stats
         if fuse_dw:
-            ops.dwgemm(w["pout"], w["ffn_dwp"], h, x, C, hid, gate=True, res=x, bias=w["pout_b"],
-                       stats_out=stats if emit else None)
+            ops.dwgemm(w["pout_s" if self._split else "pout"], w["ffn_dwp"], h, x, C, hid, gate=True, res=x,
+                       bias=w["pout_b"], stats_out=stats if emit else None, split=self._split)
         else:
             ops.dwconv3x3_gate(h, w["ffn_dw"], g, bias=w["ffn_dw_b"])
             ops.gemm1x1(w["pout"], g, x, C, hid, res=x, bias=w["pout_b"], stats_out=stats if emit else None)

@@ -115,6 +115,13 @@ int irm_dwgemm_f32(const float* wp, long w_bs, const float* dwp, const float* x,
                    const float* res, long r_bs, const float* bias, int gate, int B, int M, int K, int H, int W,
                    float* stats_out, float eps, irm_stream_t stream);
 
+/* irm_dwgemm_f32 with the 1x1 part as an fp32 emulation on the fp16 matrix cores (shared weights only).
+ * wp_split: the output conv's weight in irm_gemm1x1_f16x3_f32's hi/lo fp16 order.  The stencil outputs are
+ * scaled by 2^-4 before the split (range: |g| < 1e6), the fp32 accumulators carry that scale to the end. */
+int irm_dwgemm_f16x3_f32(const float* wp_split, const float* dwp, const float* x, long x_bs, float* y, long y_bs,
+                         const float* res, long r_bs, const float* bias, int gate, int B, int M, int K, int H, int W,
+                         float* stats_out, float eps, irm_stream_t stream);
+
 /* MDTA pass 1: per-chunk partial Gram matrices and squared norms.
  * qkv: [B][3C][N] (after qkv_dwconv; q rows [0,C), k rows [C,2C)).
  * part: workspace [B][heads][ceil(N/chunk)][c*c + 2c] floats, c = C/heads,

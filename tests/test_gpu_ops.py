@@ -222,9 +222,13 @@ DWGEMM_CASES = [
 ]
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("M,K,H,W,B,gate,res,bias,stats,per_batch", DWGEMM_CASES)
-def test_dwgemm(dev, M, K, H, W, B, gate, res, bias, stats, per_batch):
-    """Fused depth-wise 3x3 (+ gelu gate) + 1x1 conv (+ residual, + LN statistics of the result)."""
+def test_dwgemm(dev, M, K, H, W, B, gate, res, bias, stats, per_batch, split):
+    """Fused depth-wise 3x3 (+ gelu gate) + 1x1 conv (+ residual, + LN statistics of the result); split = the
+    1x1 part emulated on the fp16 matrix cores (host weights only)."""
+    if split and per_batch:
+        pytest.skip("per-sample weights come from the finalize kernel in fp32 order")
     kin = 2 * K if gate else K
     big = rnd(f"dgx{M}{K}{H}", (B, kin + 3, H, W), -1.5, 1.5)
     x = big.to(dev)[:, 1:1 + kin]
@@ -233,12 +237,13 @@ def test_dwgemm(dev, M, K, H, W, B, gate, res, bias, stats, per_batch):
     wt = rnd(f"dgw{M}{K}", (B if per_batch else 1, M, K), -0.2, 0.2)
     pb = rnd(f"dgb{M}", (M,), -0.3, 0.3) if bias else None
     r = rnd(f"dgr{M}{H}", (B, M, H, W)) if res else None
-    packed = torch.stack([_hip.pack_gemm_weight(wt[i]) for i in range(wt.shape[0])]).to(dev)
+    pack = _hip.pack_gemm_weight_split if split else _hip.pack_gemm_weight
+    packed = torch.stack([pack(wt[i]) for i in range(wt.shape[0])]).to(dev)
     dwp = _hip.pack_dw_table(w9, dwb, K, gate).to(dev)
     y = r.clone().to(dev) if res else torch.empty(B, M, H, W, device=dev)      # in place on the residual
     st = torch.zeros(B, 2, H * W, device=dev) if stats else None
     ops.dwgemm(packed, dwp, x, y, M, K, gate=gate, res=y if res else None, bias=pb.to(dev) if bias else None,
-               w_bs=packed.shape[1] if per_batch else 0, stats_out=st)
+               w_bs=packed.shape[1] if per_batch else 0, stats_out=st, split=split)
     xr = big[:, 1:1 + kin].double()
     d = F.conv2d(xr, w9.double().view(kin, 1, 3, 3), dwb.double() if bias else None, padding=1, groups=kin)
     g = F.gelu(d[:, :K]) * d[:, K:] if gate else d
