@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
                     if (LN == IRM_LN_WITHBIAS)
                         xv[kk] = fmaf(fmaf(x, rs[p], nmr[p]), lnp[s * BK + kk * 4 + g], lnp[KP + s * BK + kk * 4 + g]);
                     else if (LN == IRM_LN_BIASFREE) xv[kk] = x * rs[p] * lnp[s * BK + kk * 4 + g];
-                    else xv[kk] = x;
+                    else xv[kk] = x * 0.0625f;            // not normalised: 2^-4 keeps |x| up to 1e6 inside fp16
                 }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
@@ -488,6 +488,12 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
         if (++s == S) {
             // pass finished: (+ bias, activation, + residual) and store tiles mt0 .. mt0 + CT - 1
             const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
+            if constexpr (F16 && LN == IRM_LN_NONE) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) acc[p][c] *= 16.0f;      // undo the operand scale
+            }
             if (a.bias) {
 #pragma unroll
                 for (int c = 0; c < CT; ++c)
@@ -573,6 +579,10 @@ static int launch_ring_any(const GemmArgs& a, int B, int ygroups, int pt, hipStr
 // split-fp16 variant: 64-pixel waves, no residual
 template <int CT>
 static int launch_ring_split(const GemmArgs& a, int B, int ygroups, hipStream_t stream) {
+    if (a.R) {
+        if (a.ln_mode != IRM_LN_NONE) return IRM_EINVAL;
+        return launch_ring<2, CT, IRM_LN_NONE, true, true>(a, B, ygroups, stream);
+    }
     static const int pt = [] { const char* e = getenv("IRM_GEMM_SPLIT_PT"); return e ? atoi(e) : 4; }();
     if (pt == 2) {
         if (a.ln_mode == IRM_LN_WITHBIAS) return launch_ring<2, CT, IRM_LN_WITHBIAS, false, true>(a, B, ygroups, stream);
@@ -630,9 +640,9 @@ static int gemm_entry(const float* wp, long w_bs, const float* x, long x_bs, flo
     if (B > 65535 || ygroups > 65535) return IRM_EINVAL;
     if (split) {
         // weights packed by the caller as fp16 hi/lo pairs: only the ring kernel understands them
-        if (!vec || N < 4 || res || w_bs) return IRM_EINVAL;
+        if (!vec || N < 4 || w_bs || (res && ln_mode != IRM_LN_NONE)) return IRM_EINVAL;
         static const bool no_xres = getenv("IRM_GEMM_NO_XRES") != nullptr;
-        if (K <= 96 && !stats_out && !no_xres && B <= 65535 && (long)(N + 127) / 128 <= 2147483647L) {
+        if (K <= 96 && ln_mode != IRM_LN_NONE && !stats_out && !res && !no_xres && B <= 65535 && (long)(N + 127) / 128 <= 2147483647L) {
             const int rc = irm_gemm_xres_dispatch(wp, x, x_bs, y, y_bs, bias, stats, lnw, lnb, ln_mode, act, B, M, K, N, stream);
             if (rc != IRM_EINVAL) return rc;
         }
@@ -679,9 +689,10 @@ extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long 
 }
 
 extern "C" int irm_gemm1x1_f16x3_f32(const float* wp_split, const float* x, long x_bs, float* y, long y_bs,
-                                     const float* bias, const float* stats, const float* lnw, const float* lnb,
-                                     int ln_mode, int act, int B, int M, int K, int N, int ct, int ygroups,
-                                     float* stats_out, float eps, hipStream_t stream) {
-    return gemm_entry(wp_split, 0, x, x_bs, y, y_bs, nullptr, 0, bias, stats, lnw, lnb, ln_mode, act, B, M, K, N, ct,
-                      ygroups, stats_out, eps, nullptr, true, stream);
+                                     const float* res, long r_bs, const float* bias, const float* stats,
+                                     const float* lnw, const float* lnb, int ln_mode, int act, int B, int M, int K,
+                                     int N, int ct, int ygroups, float* stats_out, float eps,
+                                     const float* res_scale, hipStream_t stream) {
+    return gemm_entry(wp_split, 0, x, x_bs, y, y_bs, res, r_bs, bias, stats, lnw, lnb, ln_mode, act, B, M, K, N, ct,
+                      ygroups, stats_out, eps, res_scale, true, stream);
 }

@@ -122,11 +122,12 @@ def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, 
                             + (2 if stats_out is not None else 0))
     if split:
         # wp from _hip.pack_gemm_weight_split: fp32 emulation on the fp16 matrix cores (no residual)
-        assert res is None and w_bs == 0 and res_scale is None
+        assert w_bs == 0
         _launch("gemm1x1_f16x3", 2.0 * B * M * K * N, nbytes, "irm_gemm1x1_f16x3_f32", _hip.ptr(wp), _hip.ptr(x), _bs(x),
-                _hip.ptr(y), _bs(y), _hip.ptr(bias), _hip.ptr(stats), _hip.ptr(lnw), _hip.ptr(lnb), int(ln_mode),
-                int(act), B, M, K, N, ct, ygroups, _hip.ptr(stats_out), float(eps),
-                tag=f"M{M} K{K} N{N} B{B} ln{int(ln_mode)} ct{ct} yg{ygroups}")
+                _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), _hip.ptr(stats), _hip.ptr(lnw),
+                _hip.ptr(lnb), int(ln_mode), int(act), B, M, K, N, ct, ygroups, _hip.ptr(stats_out), float(eps),
+                _hip.ptr(res_scale),
+                tag=f"M{M} K{K} N{N} B{B} ln{int(ln_mode)} res{int(res is not None)} ct{ct} yg{ygroups}")
         return
     _launch("gemm1x1", 2.0 * B * M * K * N, nbytes, "irm_gemm1x1_f32", _hip.ptr(wp), int(w_bs), _hip.ptr(x), _bs(x),
             _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), _hip.ptr(stats), _hip.ptr(lnw),

@@ -288,7 +288,8 @@ class Restormer(nn.Module):
                        bias=w["pout_b"], stats_out=stats if emit else None, split=self._split)
         else:
             ops.dwconv3x3_gate(h, w["ffn_dw"], g, bias=w["ffn_dw_b"])
-            ops.gemm1x1(w["pout"], g, x, C, hid, res=x, bias=w["pout_b"], stats_out=stats if emit else None)
+            ops.gemm1x1(w["pout_s" if split else "pout"], g, x, C, hid, res=x, bias=w["pout_b"],
+                        stats_out=stats if emit else None, split=split)
         return emit
 
     @staticmethod

@@ -76,15 +76,18 @@ int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long x_bs, float
                     const float* lnb, int ln_mode, int act, int B, int M, int K, int N, int ct, int ygroups,
                     float* stats_out, float eps, const float* res_scale, irm_stream_t stream);
 
-/* The same 1x1 conv with the GEMM proper on the fp16 matrix cores as an fp32 emulation (no residual, shared
- * weights): x (after the LayerNorm prologue) is split in registers into fp16 hi + lo, the weights arrive split
- * by the host, three 16x16x16 MFMAs (lo*hi, hi*lo, hi*hi) accumulate in fp32 - 2^-21 relative per product.
+/* The same 1x1 conv with the GEMM proper on the fp16 matrix cores as an fp32 emulation (shared weights; a
+ * residual only without the LayerNorm prologue, as in irm_gemm1x1_f32): x (after the LayerNorm prologue) is
+ * split in registers into fp16 hi + lo, the weights arrive split by the host, three MFMAs (lo*hi, hi*lo, hi*hi)
+ * accumulate in fp32 - 2^-21 relative per product.
  * wp_split: same size as wp; per (mtile, 16-channel stage) 64 lanes x 4 fp16 hi, then 64 lanes x 4 fp16 lo,
  *   lane (g = lane>>4, m = lane&15) holds W[16 mtile + m][16 stage + 4 j + g], j = 0..3  (zero padded).
- * Inputs beyond the fp16 range (|x| > 65504 after the LayerNorm) are not supported. */
-int irm_gemm1x1_f16x3_f32(const float* wp_split, const float* x, long x_bs, float* y, long y_bs, const float* bias,
-                          const float* stats, const float* lnw, const float* lnb, int ln_mode, int act, int B,
-                          int M, int K, int N, int ct, int ygroups, float* stats_out, float eps, irm_stream_t stream);
+ * Range: a LayerNorm output cannot leave fp16; inputs without the prologue are scaled by 2^-4 for the split
+ * (|x| < 1e6), the accumulators are rescaled before bias / residual. */
+int irm_gemm1x1_f16x3_f32(const float* wp_split, const float* x, long x_bs, float* y, long y_bs, const float* res,
+                          long r_bs, const float* bias, const float* stats, const float* lnw, const float* lnb,
+                          int ln_mode, int act, int B, int M, int K, int N, int ct, int ygroups, float* stats_out,
+                          float eps, const float* res_scale, irm_stream_t stream);
 
 /* Depth-wise 3x3 convolution, zero pad 1: y[b][c] = act(dw3x3(x[b][c]; w[c]) + bias[c]).
  * Replaces Attention.qkv_dwconv (restormer.py:106) and MaIR's conv2d+SiLU.

@@ -211,6 +211,25 @@ def test_gemm1x1_f16x3(dev, M, K, H, W, B, ln, bias, ct):
     assert e16 < 2e-5 and e16 < 8 * max(e32, 1e-7)
 
 
+@pytest.mark.parametrize("M,K,H,W,B,scale", [(192, 510, 8, 16, 2, 1.0), (384, 1021, 8, 8, 1, 1.0), (96, 255, 16, 16, 1, 3000.0)])
+def test_gemm1x1_f16x3_residual(dev, M, K, H, W, B, scale):
+    """The emulated GEMM without the LayerNorm prologue (inputs pre-scaled by 2^-4 for the fp16 split) + bias +
+    residual, in place; the last case feeds activations of magnitude 3000."""
+    x = rnd(f"rx{M}{K}", (B, K, H, W), -2, 3) * scale
+    w = rnd(f"rw{M}{K}", (M, K), -0.2, 0.2)
+    bv = rnd(f"rb{M}", (M,), -0.3, 0.3)
+    r = rnd(f"rr{M}", (B, M, H, W))
+    ref = torch.einsum("mk,bkhw->bmhw", w.double(), x.double()) + bv.double().view(1, M, 1, 1) + r.double()
+    y = r.clone().to(dev)
+    ops.gemm1x1(_hip.pack_gemm_weight_split(w).to(dev), x.to(dev), y, M, K, res=y, bias=bv.to(dev), split=True)
+    y32 = r.clone().to(dev)
+    ops.gemm1x1(_hip.pack_gemm_weight(w).to(dev), x.to(dev), y32, M, K, res=y32, bias=bv.to(dev))
+    e16 = (y.cpu().double() - ref).abs().max().item() / scale
+    e32 = (y32.cpu().double() - ref).abs().max().item() / scale
+    print(f"M{M} K{K} scale {scale:g}: max-abs/scale vs float64  f16x3 {e16:.3e}   f32 {e32:.3e}")
+    assert e16 < 4e-5 and e16 < 8 * max(e32, 1e-7)
+
+
 DWGEMM_CASES = [
     # M, K, H, W, B, gate, res, bias, stats, per_batch
     (48, 127, 19, 36, 2, True, True, False, True, False),
