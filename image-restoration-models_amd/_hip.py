@@ -24,13 +24,14 @@ SIGNATURES = {
     "irm_version": [],
     "irm_ln_stats_f32": [_P, _L, _P, _I, _I, _I, _F, _P],
     "irm_gemm1x1_f32": [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P],
-    "irm_gemm1x1_f16x3_f32": [_P, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P],
+    "irm_gemm1x1_f16x3_f32": [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P],
     "irm_dwconv3x3_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
     "irm_dwconv3x3_gate_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "irm_dwgemm_f32": [_P, _L, _P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _F, _P],
-    "irm_dwgemm_f16x3_f32": [_P, _P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _F, _P],
+    "irm_dwgemm_f16x3_f32": [_P, _L, _P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _F, _P],
     "irm_mdta_gram_f32": [_P, _L, _P, _I, _I, _I, _I, _I, _P],
     "irm_mdta_finalize_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "irm_mdta_finalize_f16x3_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "irm_conv3x3_f32": [_P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "irm_tile_extract": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "irm_chan_stats_f32": [_P, _L, _P, _I, _I, _I, _F, _P],

@@ -399,7 +399,6 @@ static int dwgemm_entry(const float* wp, long w_bs, const float* dwp, const floa
     a.tiles = a.tiles_x * ((H + 7) / 8);
     { const char* e = getenv("IRM_DWGEMM_DBG"); a.dbg = e ? atoi(e) : 0; }
     if (split) {
-        if (w_bs) return IRM_EINVAL;               // the split weights come from the host: shared by all samples
         if (a.mtiles <= 3) return gate ? dg_launch<3, true, 4, true>(a, B, stream) : dg_launch<3, false, 4, true>(a, B, stream);
         return gate ? dg_launch<6, true, 4, true>(a, B, stream) : dg_launch<6, false, 4, true>(a, B, stream);
     }
@@ -420,9 +419,9 @@ extern "C" int irm_dwgemm_f32(const float* wp, long w_bs, const float* dwp, cons
                         stream);
 }
 
-extern "C" int irm_dwgemm_f16x3_f32(const float* wp_split, const float* dwp, const float* x, long x_bs, float* y,
+extern "C" int irm_dwgemm_f16x3_f32(const float* wp_split, long w_bs, const float* dwp, const float* x, long x_bs, float* y,
                                     long y_bs, const float* res, long r_bs, const float* bias, int gate, int B, int M,
                                     int K, int H, int W, float* stats_out, float eps, hipStream_t stream) {
-    return dwgemm_entry(wp_split, 0, dwp, x, x_bs, y, y_bs, res, r_bs, bias, gate, B, M, K, H, W, stats_out, eps, true,
+    return dwgemm_entry(wp_split, w_bs, dwp, x, x_bs, y, y_bs, res, r_bs, bias, gate, B, M, K, H, W, stats_out, eps, true,
                         stream);
 }

@@ -640,9 +640,9 @@ static int gemm_entry(const float* wp, long w_bs, const float* x, long x_bs, flo
     if (B > 65535 || ygroups > 65535) return IRM_EINVAL;
     if (split) {
         // weights packed by the caller as fp16 hi/lo pairs: only the ring kernel understands them
-        if (!vec || N < 4 || w_bs || (res && ln_mode != IRM_LN_NONE)) return IRM_EINVAL;
+        if (!vec || N < 4 || (res && ln_mode != IRM_LN_NONE)) return IRM_EINVAL;
         static const bool no_xres = getenv("IRM_GEMM_NO_XRES") != nullptr;
-        if (K <= 96 && ln_mode != IRM_LN_NONE && !stats_out && !res && !no_xres && B <= 65535 && (long)(N + 127) / 128 <= 2147483647L) {
+        if (K <= 96 && ln_mode != IRM_LN_NONE && !stats_out && !res && !w_bs && !no_xres && B <= 65535 && (long)(N + 127) / 128 <= 2147483647L) {
             const int rc = irm_gemm_xres_dispatch(wp, x, x_bs, y, y_bs, bias, stats, lnw, lnb, ln_mode, act, B, M, K, N, stream);
             if (rc != IRM_EINVAL) return rc;
         }
@@ -688,11 +688,11 @@ extern "C" int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long 
                       ygroups, stats_out, eps, res_scale, false, stream);
 }
 
-extern "C" int irm_gemm1x1_f16x3_f32(const float* wp_split, const float* x, long x_bs, float* y, long y_bs,
+extern "C" int irm_gemm1x1_f16x3_f32(const float* wp_split, long w_bs, const float* x, long x_bs, float* y, long y_bs,
                                      const float* res, long r_bs, const float* bias, const float* stats,
                                      const float* lnw, const float* lnb, int ln_mode, int act, int B, int M, int K,
                                      int N, int ct, int ygroups, float* stats_out, float eps,
                                      const float* res_scale, hipStream_t stream) {
-    return gemm_entry(wp_split, 0, x, x_bs, y, y_bs, res, r_bs, bias, stats, lnw, lnb, ln_mode, act, B, M, K, N, ct,
+    return gemm_entry(wp_split, w_bs, x, x_bs, y, y_bs, res, r_bs, bias, stats, lnw, lnb, ln_mode, act, B, M, K, N, ct,
                       ygroups, stats_out, eps, res_scale, true, stream);
 }

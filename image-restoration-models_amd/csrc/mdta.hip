@@ -365,6 +365,7 @@ struct FinArgs {
     float* mfold;               // [B][mtiles][ksteps][64]
     float* attn;                // optional [B][heads][c][c] (tests) or null
     int C, heads, ksteps;
+    int split;                  // mfold in irm_gemm1x1_f16x3_f32's fp16 hi/lo order instead of packed fp32
 };
 
 __global__ __launch_bounds__(256) void mdta_finalize_kernel(FinArgs a) {
@@ -418,14 +419,23 @@ __global__ __launch_bounds__(256) void mdta_finalize_kernel(FinArgs a) {
         float acc = 0.0f;
         for (int i = 0; i < c; ++i) acc += wrow[i] * G[i * c + j];
         const int kcol = head * c + j;
-        const int ln = (co & 15) + 16 * (kcol & 3);
-        mf[((long)(co >> 4) * a.ksteps + (kcol >> 2)) * 64 + ln] = acc;
+        if (a.split) {
+            // record of (mtile, 16-channel stage): 64 lanes x 4 hi halves, then 64 lanes x 4 lo halves;
+            // lane (g, m) slot jj holds W[m][16 stage + 4 jj + g]
+            _Float16* rec = reinterpret_cast<_Float16*>(mf + ((long)(co >> 4) * (a.ksteps >> 2) + (kcol >> 4)) * 256);
+            const int slot = ((kcol & 3) * 16 + (co & 15)) * 4 + ((kcol & 15) >> 2);
+            const _Float16 hi = (_Float16)acc;
+            rec[slot] = hi;
+            rec[256 + slot] = (_Float16)(acc - (float)hi);
+        } else {
+            const int ln = (co & 15) + 16 * (kcol & 3);
+            mf[((long)(co >> 4) * a.ksteps + (kcol >> 2)) * 64 + ln] = acc;
+        }
     }
 }
 
-extern "C" int irm_mdta_finalize_f32(const float* part, float* gsum, const float* temperature,
-                                     const float* wout, float* mfold, float* attn, int B, int C, int heads,
-                                     int nchunk, hipStream_t stream) {
+static int mdta_finalize(const float* part, float* gsum, const float* temperature, const float* wout, float* mfold,
+                         float* attn, int B, int C, int heads, int nchunk, int split, hipStream_t stream) {
     if (!part || !gsum || !temperature || !wout || !mfold || B <= 0 || C <= 0 || heads <= 0 || nchunk <= 0)
         return IRM_EINVAL;
     if (C % heads || (long)B * heads > 65535) return IRM_EINVAL;
@@ -439,7 +449,19 @@ extern "C" int irm_mdta_finalize_f32(const float* part, float* gsum, const float
     if (rc != IRM_OK) return rc;
     // padded rows/cols of the packed matrix stay zero: the caller clears mfold once at allocation
     // (C is a multiple of 16 at every Restormer level, so normally there is no padding at all)
-    FinArgs a{gsum, temperature, wout, mfold, attn, C, heads, 4 * ((C + 15) / 16)};
+    FinArgs a{gsum, temperature, wout, mfold, attn, C, heads, 4 * ((C + 15) / 16), split};
     hipLaunchKernelGGL(mdta_finalize_kernel, dim3(heads, B, 8), dim3(256), lds, stream, a);
     return irm_launch_status();
+}
+
+extern "C" int irm_mdta_finalize_f32(const float* part, float* gsum, const float* temperature,
+                                     const float* wout, float* mfold, float* attn, int B, int C, int heads,
+                                     int nchunk, hipStream_t stream) {
+    return mdta_finalize(part, gsum, temperature, wout, mfold, attn, B, C, heads, nchunk, 0, stream);
+}
+
+extern "C" int irm_mdta_finalize_f16x3_f32(const float* part, float* gsum, const float* temperature,
+                                           const float* wout, float* mfold_split, float* attn, int B, int C,
+                                           int heads, int nchunk, hipStream_t stream) {
+    return mdta_finalize(part, gsum, temperature, wout, mfold_split, attn, B, C, heads, nchunk, 1, stream);
 }

@@ -122,8 +122,7 @@ def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, 
                             + (2 if stats_out is not None else 0))
     if split:
         # wp from _hip.pack_gemm_weight_split: fp32 emulation on the fp16 matrix cores (no residual)
-        assert w_bs == 0
-        _launch("gemm1x1_f16x3", 2.0 * B * M * K * N, nbytes, "irm_gemm1x1_f16x3_f32", _hip.ptr(wp), _hip.ptr(x), _bs(x),
+        _launch("gemm1x1_f16x3", 2.0 * B * M * K * N, nbytes, "irm_gemm1x1_f16x3_f32", _hip.ptr(wp), int(w_bs), _hip.ptr(x), _bs(x),
                 _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), _hip.ptr(stats), _hip.ptr(lnw),
                 _hip.ptr(lnb), int(ln_mode), int(act), B, M, K, N, ct, ygroups, _hip.ptr(stats_out), float(eps),
                 _hip.ptr(res_scale),
@@ -172,8 +171,7 @@ def dwgemm(wp, dwp, x, y, M: int, K: int, *, gate: bool, res=None, bias=None, w_
     flops = B * N * (2.0 * M * K + (36.0 if gate else 18.0) * K)
     if split:
         # wp from _hip.pack_gemm_weight_split: the 1x1 part as an fp32 emulation on the fp16 matrix cores
-        assert w_bs == 0
-        _launch("dwgemm_f16x3", flops, nbytes, "irm_dwgemm_f16x3_f32", _hip.ptr(wp), _hip.ptr(dwp), _hip.ptr(x), _bs(x),
+        _launch("dwgemm_f16x3", flops, nbytes, "irm_dwgemm_f16x3_f32", _hip.ptr(wp), int(w_bs), _hip.ptr(dwp), _hip.ptr(x), _bs(x),
                 _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), int(bool(gate)), B, M, K, H, W,
                 _hip.ptr(stats_out), float(eps), tag=f"M{M} K{K} {H}x{W} B{B} gate{int(bool(gate))}")
         return
@@ -195,8 +193,9 @@ def mdta_plan(B: int, C: int, heads: int, N: int):
     return chunk, -(-N // chunk), c * c + 2 * c
 
 
-def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, attn=None):
-    """Gram pass + finalize: mfold[b] <- packed(W_out @ blockdiag(softmax(...))) (restormer.py:115-131)."""
+def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, attn=None, split: bool = False):
+    """Gram pass + finalize: mfold[b] <- packed(W_out @ blockdiag(softmax(...))) (restormer.py:115-131);
+    split: in the fp16 hi/lo order of the emulated GEMM kernels."""
     _chk(qkv, "qkv")
     B, _, H, W = qkv.shape
     N = H * W
@@ -205,7 +204,8 @@ def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, att
     c = C // heads
     _launch("mdta_gram", 2.0 * B * heads * c * c * N, 8.0 * B * C * N, "irm_mdta_gram_f32", _hip.ptr(qkv), _bs(qkv),
             _hip.ptr(part), B, C, heads, N, chunk, tag=f"C{C} h{heads} N{N} B{B} chunk{chunk}")
-    _launch("mdta_finalize", 2.0 * B * C * C * c, 4.0 * B * (heads * nchunk * rec + C * C), "irm_mdta_finalize_f32",
+    _launch("mdta_finalize", 2.0 * B * C * C * c, 4.0 * B * (heads * nchunk * rec + C * C),
+            "irm_mdta_finalize_f16x3_f32" if split else "irm_mdta_finalize_f32",
             _hip.ptr(part), _hip.ptr(gsum), _hip.ptr(temperature), _hip.ptr(wout), _hip.ptr(mfold), _hip.ptr(attn),
             B, C, heads, nchunk, tag=f"C{C} h{heads} nchunk{nchunk} B{B}")
 

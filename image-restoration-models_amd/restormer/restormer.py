@@ -268,13 +268,14 @@ class Restormer(nn.Module):
         if mfold is None or mfold.device != dev:
             mfold = torch.zeros(B * mfold_n, dtype=torch.float32, device=dev)
             ws[("mfold", C, B)] = mfold
-        ops.mdta_fold(qkv2, part, gsum, w["temp"], w["wout"], mfold, C, heads)
+        # the folded per-image matrix in the order of the kernel that applies it (fp16 hi/lo when emulated)
+        ops.mdta_fold(qkv2, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=split)
         if fuse_dw:
             ops.dwgemm(mfold, w["v_dwp"], qkv[:, 2 * C:], x, C, C, gate=False, res=x, bias=w["wout_b"],
-                       w_bs=mfold_n, stats_out=stats if fuse else None)
+                       w_bs=mfold_n, stats_out=stats if fuse else None, split=split)
         else:
             ops.gemm1x1(mfold, qkv2[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n,
-                        stats_out=stats if fuse else None)
+                        stats_out=stats if fuse else None, split=split)
         # --- feed-forward branch: x += project_out(gelu(dw(h1)) * dw(h2))   (restormer.py:88-93, 148)
         h = big_a[:B * 2 * hid * N].view(B, 2 * hid, H, W)
         g = big_b[:B * hid * N].view(B, hid, H, W)
@@ -284,8 +285,8 @@ class Restormer(nn.Module):
                     lnb=w["n2b"], ln_mode=blk.norm2.mode, split=split)
         emit = fuse and want_stats
         if fuse_dw:
-            ops.dwgemm(w["pout_s" if self._split else "pout"], w["ffn_dwp"], h, x, C, hid, gate=True, res=x,
-                       bias=w["pout_b"], stats_out=stats if emit else None, split=self._split)
+            ops.dwgemm(w["pout_s" if split else "pout"], w["ffn_dwp"], h, x, C, hid, gate=True, res=x,
+                       bias=w["pout_b"], stats_out=stats if emit else None, split=split)
         else:
             ops.dwconv3x3_gate(h, w["ffn_dw"], g, bias=w["ffn_dw_b"])
             ops.gemm1x1(w["pout_s" if split else "pout"], g, x, C, hid, res=x, bias=w["pout_b"],

@@ -84,7 +84,7 @@ int irm_gemm1x1_f32(const float* wp, long w_bs, const float* x, long x_bs, float
  *   lane (g = lane>>4, m = lane&15) holds W[16 mtile + m][16 stage + 4 j + g], j = 0..3  (zero padded).
  * Range: a LayerNorm output cannot leave fp16; inputs without the prologue are scaled by 2^-4 for the split
  * (|x| < 1e6), the accumulators are rescaled before bias / residual. */
-int irm_gemm1x1_f16x3_f32(const float* wp_split, const float* x, long x_bs, float* y, long y_bs, const float* res,
+int irm_gemm1x1_f16x3_f32(const float* wp_split, long w_bs, const float* x, long x_bs, float* y, long y_bs, const float* res,
                           long r_bs, const float* bias, const float* stats, const float* lnw, const float* lnb,
                           int ln_mode, int act, int B, int M, int K, int N, int ct, int ygroups, float* stats_out,
                           float eps, const float* res_scale, irm_stream_t stream);
@@ -118,10 +118,10 @@ int irm_dwgemm_f32(const float* wp, long w_bs, const float* dwp, const float* x,
                    const float* res, long r_bs, const float* bias, int gate, int B, int M, int K, int H, int W,
                    float* stats_out, float eps, irm_stream_t stream);
 
-/* irm_dwgemm_f32 with the 1x1 part as an fp32 emulation on the fp16 matrix cores (shared weights only).
+/* irm_dwgemm_f32 with the 1x1 part as an fp32 emulation on the fp16 matrix cores.
  * wp_split: the output conv's weight in irm_gemm1x1_f16x3_f32's hi/lo fp16 order.  The stencil outputs are
  * scaled by 2^-4 before the split (range: |g| < 1e6), the fp32 accumulators carry that scale to the end. */
-int irm_dwgemm_f16x3_f32(const float* wp_split, const float* dwp, const float* x, long x_bs, float* y, long y_bs,
+int irm_dwgemm_f16x3_f32(const float* wp_split, long w_bs, const float* dwp, const float* x, long x_bs, float* y, long y_bs,
                          const float* res, long r_bs, const float* bias, int gate, int B, int M, int K, int H, int W,
                          float* stats_out, float eps, irm_stream_t stream);
 
@@ -144,6 +144,11 @@ int irm_mdta_gram_f32(const float* qkv, long bs, float* part, int B, int C, int 
  * irm_gemm1x1_f32(mfold, v, res = block input). */
 int irm_mdta_finalize_f32(const float* part, float* gsum, const float* temperature, const float* wout,
                           float* mfold, float* attn, int B, int C, int heads, int nchunk, irm_stream_t stream);
+/* Same, with the folded matrix written in irm_gemm1x1_f16x3_f32's fp16 hi/lo order (same number of floats per
+ * sample), for irm_dwgemm_f16x3_f32 / irm_gemm1x1_f16x3_f32 with w_bs = that size. */
+int irm_mdta_finalize_f16x3_f32(const float* part, float* gsum, const float* temperature, const float* wout,
+                                float* mfold_split, float* attn, int B, int C, int heads, int nchunk,
+                                irm_stream_t stream);
 
 /* Dense 3x3 convolution, stride 1, zero pad 1, implicit GEMM on the f32 MFMA:
  *   v = conv(x)[co] + bias[co]; if relu1: v = max(v,0);

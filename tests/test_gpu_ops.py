@@ -246,8 +246,6 @@ DWGEMM_CASES = [
 def test_dwgemm(dev, M, K, H, W, B, gate, res, bias, stats, per_batch, split):
     """Fused depth-wise 3x3 (+ gelu gate) + 1x1 conv (+ residual, + LN statistics of the result); split = the
     1x1 part emulated on the fp16 matrix cores (host weights only)."""
-    if split and per_batch:
-        pytest.skip("per-sample weights come from the finalize kernel in fp32 order")
     kin = 2 * K if gate else K
     big = rnd(f"dgx{M}{K}{H}", (B, kin + 3, H, W), -1.5, 1.5)
     x = big.to(dev)[:, 1:1 + kin]
@@ -305,6 +303,13 @@ def test_mdta_fold(dev, B, C, heads, H, W):
     y = torch.empty(B, C, H, W, device=dev)
     ops.gemm1x1(mfold, qg[:, 2 * C:], y, C, C, w_bs=ops.mfold_numel(C))
     assert (y.cpu().double() - ref).abs().max() < TOL
+    if N % 4 == 0:
+        # the same fold written in fp16 hi/lo order and applied by the emulated GEMM
+        ops.mdta_fold(qg, part, gsum, temp.to(dev), wout.to(dev), mfold, C, heads, split=True)
+        y2 = torch.empty(B, C, H, W, device=dev)
+        ops.gemm1x1(mfold, qg[:, 2 * C:], y2, C, C, w_bs=ops.mfold_numel(C), split=True)
+        assert (y2.cpu().double() - ref).abs().max() < TOL
+        assert (y2 - y).abs().max() < 2e-5
 
 
 CONV_CASES = [
