@@ -96,7 +96,7 @@ def pmc_traffic(pattern):
     MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_traffic.py).  None when the file is absent: the
     counters cannot be read from inside an unprofiled run."""
     import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "f_split_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "g_final_pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
