@@ -94,13 +94,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // outputs as register pairs (o0,o1)[, (o2,o3)].  kk[t] holds tap t twice (k,k); bias first, then the taps row
 // by row, as dw_apply in elementwise.hip.  Lanes of a wave read consecutive columns of the halo image: no LDS
 // bank conflicts.
-template <int PT>
+template <int PT, int RF>
 __device__ __forceinline__ void dg_stencil(const float* img, const v2f (&kk)[9], v2f bias, v2f (&o)[PT / 2]) {
     v2f rp[PT + 1][3];                             // rp[d][dx] = rows d and d+1 at column dx
 #pragma unroll
     for (int d = 0; d < PT + 1; ++d)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) rp[d][dx] = (v2f){img[d * 40 + dx], img[(d + 1) * 40 + dx]};
+        for (int dx = 0; dx < 3; ++dx) rp[d][dx] = (v2f){img[d * RF + dx], img[(d + 1) * RF + dx]};
 #pragma unroll
     for (int h = 0; h < PT / 2; ++h) {
         v2f s = bias;
@@ -140,18 +140,26 @@ __device__ __forceinline__ v2f dg_gelu2(v2f x) {
 // extra, partly masked DMA instruction per wave and stage, into a double-buffered area next to the ring.
 typedef _Float16 dg_h4 __attribute__((ext_vector_type(4)));
 
-template <int CT, bool GATE, int NS, int PT, bool F16 = false>
-__global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 2) void dwgemm_kernel(DwGemmArgs a) {
-    constexpr int NT = PT == 4 ? 256 : 512;        // threads per workgroup
+// TW = tile width (32 or 64 pixels; 8 rows): the halo columns cost a 64-byte sector per row and side for one
+// pixel each, so a 64-wide tile (8 waves) moves 1.5x instead of 2x the bytes of its rows
+template <int CT, bool GATE, int NS, int PT, bool F16 = false, int TW = 32>
+__global__ __launch_bounds__((PT == 4 ? 256 : 512) * (TW / 32), TW == 64 ? 1 : (PT == 4 ? (CT <= 3 ? 3 : 2) : 2))
+void dwgemm_kernel(DwGemmArgs a) {
+    constexpr int CH = TW / 4 + 2;                 // 16-byte chunks per halo row
+    constexpr int RF = CH * 4, PL = 10 * RF;       // floats per halo row / plane
+    constexpr int NWX = TW / 16;                   // wave columns
+    constexpr int NT = (PT == 4 ? 256 : 512) * (TW / 32);   // threads per workgroup
     constexpr int NP = GATE ? 8 : 4;               // halo planes per stage
     constexpr int DWS = GATE ? 40 : 20;            // depth-wise coefficients per channel (floats, each twice)
-    constexpr int XC = NP * 100, WC = F16 ? 0 : CT * 16;   // 16-byte chunks per stage (F16: weights bypass the ring)
+    constexpr int XC = NP * 10 * CH, WC = F16 ? 0 : CT * 16;   // 16-byte chunks per stage (F16: weights bypass the ring)
     constexpr int TC = XC + WC + DWS;
     constexpr int R = (TC + NT - 1) / NT;          // DMA instructions per lane per stage
     constexpr int STG = R * NT * 4;                // floats per stage
     constexpr int RW = R + (F16 ? 1 : 0);          // DMA instructions per wave and stage
     static_assert((NS - 2) * RW <= 63, "vmcnt field");
-    static_assert(!F16 || (PT == 4 && CT * 4 <= 64), "F16 variant: 4 waves, one masked weight instruction each");
+    constexpr int LW = CT * 16 / (NT / 64);        // F16: weight pieces per wave and stage
+    static_assert(!F16 || (PT == 4 && (CT * 16) % (NT / 64) == 0 && LW <= 64), "F16 variant: one masked weight instruction per wave");
+    static_assert(TW == 32 || (PT == 4 && F16), "64-wide tiles: emulated variant only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* warea = smem + NS * STG;                // F16: [group parity][quarter][CT * 64] floats
 
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
     const int per = (a.tiles + 7) >> 3;
     const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (tile >= a.tiles) return;
-    const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * 32;
+    const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * TW;
     const long plane = (long)a.H * a.W;
     const float* X = a.X + (long)b * a.x_bs;
     const float* Wp = a.Wp + (long)b * a.w_bs;
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
         const int q = j * NT + tid;
         base[j] = dg_zero_page; stride[j] = 0; lim[j] = 0;
         if (q < XC) {
-            const int pl = q / 100, rem = q - pl * 100, row = rem / 10, chunk = rem - row * 10;
+            const int pl = q / (10 * CH), rem = q - pl * (10 * CH), row = rem / CH, chunk = rem - row * CH;
             const int gy = ty0 - 1 + row, gx = tx0 - 4 + chunk * 4;
             const int ch = pl & 3, set = pl >> 2;
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
@@ -217,13 +225,13 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
         }
         if constexpr (F16) {
             // quarter (s & 3) of the split weights of group s >> 2: CT*16 pieces of 16 bytes, CT*4 lanes per wave
-            if (lane < CT * 4) {
-                const int cq = wave * (CT * 4) + lane, ct = cq >> 4;
+            if (lane < LW) {
+                const int cq = wave * LW + lane, ct = cq >> 4;
                 const float* src = ct < a.mtiles
                     ? Wp + ((long)ct * groups + (s >> 2)) * 256 + (s & 3) * 64 + (cq & 15) * 4 : dg_zero_page;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                     (__attribute__((address_space(3))) void*)(warea + ((s >> 2) & 1) * (CT * 256) + (s & 3) * (CT * 64) +
-                                                              wave * (CT * 16)), 16, 0, 0);
+                                                              wave * (LW * 4)), 16, 0, 0);
             }
         }
     };
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
     long pix[PT];
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
-        const int y = ty0 + (wave >> 1) * PT + q, x = tx0 + 16 * (wave & 1) + 4 * g;
+        const int y = ty0 + (wave / NWX) * PT + q, x = tx0 + 16 * (wave % NWX) + 4 * g;
         pix[q] = (y < a.H && x < a.W) ? (long)y * a.W + x : -1;
     }
     f32x4 acc[PT][CT];
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
 
     // A-operand pixels of this lane: column 16*(wave&1) + i, rows PT*(wave>>1) + p, p < PT (a wave owns a
     // PT x 16 patch); img_off = top-left tap of the first pixel in the halo image
-    const int img_off = g * 400 + (wave >> 1) * (PT * 40) + 16 * (wave & 1) + i + 3;
+    const int img_off = g * PL + (wave / NWX) * (PT * RF) + 16 * (wave % NWX) + i + 3;
 
     float ag[4][PT];                               // F16: stencil outputs of the 4 stages of a group
     for (int s = 0; s < SL; ++s) {
@@ -282,12 +290,12 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
             v2f ka[9], oa[PT / 2];
 #pragma unroll
             for (int t = 0; t < 9; ++t) ka[t] = dk[t];
-            dg_stencil<PT>(xb + img_off, ka, dk[9], oa);
+            dg_stencil<PT, RF>(xb + img_off, ka, dk[9], oa);
             if (GATE) {
                 v2f kb[9], ob[PT / 2];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) kb[t] = dk[10 + t];
-                dg_stencil<PT>(xb + img_off + 1600, kb, dk[19], ob);
+                dg_stencil<PT, RF>(xb + img_off + 4 * PL, kb, dk[19], ob);
 #pragma unroll
                 for (int h = 0; h < PT / 2; ++h) oa[h] = dg_gelu2(oa[h]) * ob[h];
             }
@@ -363,22 +371,24 @@ __global__ __launch_bounds__(PT == 4 ? 256 : 512, PT == 4 ? (CT <= 3 ? 3 : 2) : 
     }
 }
 
-template <int CT, bool GATE, int PT, bool F16 = false>
-static int dg_launch(const DwGemmArgs& a, int B, hipStream_t stream) {
+template <int CT, bool GATE, int PT, bool F16 = false, int TW = 32>
+static int dg_launch(DwGemmArgs a, int B, hipStream_t stream) {
     constexpr int NS = 3;                          // deeper rings (4..6) measured no faster: occupancy matters more
-    constexpr int NT = PT == 4 ? 256 : 512;
-    constexpr int TC = (GATE ? 800 : 400) + (F16 ? 0 : CT * 16) + (GATE ? 40 : 20);
+    constexpr int NT = (PT == 4 ? 256 : 512) * (TW / 32);
+    constexpr int TC = (GATE ? 8 : 4) * 10 * (TW / 4 + 2) + (F16 ? 0 : CT * 16) + (GATE ? 40 : 20);
     constexpr int R = (TC + NT - 1) / NT;
     const size_t lds = (size_t)NS * R * NT * 16 + (F16 ? 2 * CT * 1024 : 0);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgemm_kernel<CT, GATE, NS, PT, F16>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgemm_kernel<CT, GATE, NS, PT, F16, TW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return IRM_ELAUNCH;
         configured = true;
     }
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles = a.tiles_x * ((a.H + 7) / 8);
     const int per = (a.tiles + 7) >> 3;
-    hipLaunchKernelGGL((dwgemm_kernel<CT, GATE, NS, PT, F16>), dim3(per * 8, B), dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL((dwgemm_kernel<CT, GATE, NS, PT, F16, TW>), dim3(per * 8, B), dim3(NT), lds, stream, a);
     return irm_launch_status();
 }
 
@@ -399,6 +409,13 @@ static int dwgemm_entry(const float* wp, long w_bs, const float* dwp, const floa
     a.tiles = a.tiles_x * ((H + 7) / 8);
     { const char* e = getenv("IRM_DWGEMM_DBG"); a.dbg = e ? atoi(e) : 0; }
     if (split) {
+        // 64-wide tiles (IRM_DWGEMM_TW=64): fewer halo sectors, but measured 5-8 % slower than 32-wide ones
+        static const int tw_env = [] { const char* e = getenv("IRM_DWGEMM_TW"); return e ? atoi(e) : 0; }();
+        const bool wide = tw_env == 64;
+        if (wide) {
+            if (a.mtiles <= 3) return gate ? dg_launch<3, true, 4, true, 64>(a, B, stream) : dg_launch<3, false, 4, true, 64>(a, B, stream);
+            return gate ? dg_launch<6, true, 4, true, 64>(a, B, stream) : dg_launch<6, false, 4, true, 64>(a, B, stream);
+        }
         if (a.mtiles <= 3) return gate ? dg_launch<3, true, 4, true>(a, B, stream) : dg_launch<3, false, 4, true>(a, B, stream);
         return gate ? dg_launch<6, true, 4, true>(a, B, stream) : dg_launch<6, false, 4, true>(a, B, stream);
     }
