@@ -183,8 +183,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if os.environ.get("IRM_GEMM_EXACT") else
-                     "f32 (LayerNorm-prologue 1x1 convs: fp32 emulated by 3 fp16 MFMAs with fp32 accumulation, "
-                     "error vs float64 <= the exact-f32 kernel's; everything else exact f32)",
+                     "f32 (1x1 convs: fp32 emulated by 3 fp16 MFMAs on hi/lo operand splits with fp32 accumulation, "
+                     "error vs float64 <= the exact-f32 kernel's; everything else exact f32; IRM_GEMM_EXACT=1: "
+                     "f32 MFMA everywhere)",
             "data": "synthetic",
             "config": {"workload": "Restormer motion-deblur (WithBias LN, 26.13M params, synthetic weights seed 42) on "
                                    "1280x720x3 uint8 GoPro-shaped synthetic frames; 6 tiles 512x512 (overlap 96) per "
