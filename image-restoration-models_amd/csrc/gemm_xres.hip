@@ -33,7 +33,7 @@ __device__ __attribute__((noinline)) float xr_act(float v, int act) { return irm
 typedef _Float16 xr_h8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ xr_h8 xr_cat(xr_h4 a, xr_h4 b) {
-    return (xr_h8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);      // register-tuple concatenation, no moves
 }
 
 // KT = 16-channel stages of the input (even: two of them feed one 16x16x32 MFMA), CT = output tiles per pass,
@@ -55,8 +55,7 @@ __global__ __launch_bounds__((16 / WP + 1) * 64, 1) void gemm_xres_kernel(XresAr
     static_assert(KT % 2 == 0, "two 16-channel stages per MFMA");
     static_assert((NS - 2) * CT * 2 <= 63, "vmcnt field");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* ah = smem;                              // [stage][ptile][lane][4 halves]
-    float* al = smem + AH;
+    float* ah = smem;                              // [stage pair][ptile][hi even, hi odd, lo even, lo odd][lane][4 halves]
     float* wring = smem + 2 * AH;
     float* lnp = wring + NS * WST;                 // [2][16 KT] LayerNorm weight, bias (zero padded)
 
@@ -85,10 +84,12 @@ __global__ __launch_bounds__((16 / WP + 1) * 64, 1) void gemm_xres_kernel(XresAr
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const int mt = min(ci * CT + ct, a.mtiles - 1);
-                const float* src = a.Wp + ((long)mt * a.stages + 2 * t) * 256 + lane * 4;
+                // LDS image of a tile: [hi stage 2t | hi stage 2t+1 | lo 2t | lo 2t+1] (512 B each), so that the
+                // two halves of an 8-half operand sit one ds_read2st64_b64 apart and land in adjacent registers
+                const float* src = a.Wp + ((long)mt * a.stages + 2 * t + (lane >> 5)) * 256 + (lane & 31) * 4;
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + h * 256),
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + h * 128),
                                                      (__attribute__((address_space(3))) void*)(dst + ct * 512 + h * 256),
                                                      16, 0, 0);
             }
@@ -143,9 +144,10 @@ __global__ __launch_bounds__((16 / WP + 1) * 64, 1) void gemm_xres_kernel(XresAr
                 h[j] = (_Float16)x;
                 l[j] = (_Float16)(x - (float)h[j]);
             }
-            const int off = ((s * NPT + pt) * 64 + gg * 16 + i) * 2;     // floats (4 halves = 2 floats)
+            // image of a (stage pair, pixel tile): [hi even stage | hi odd stage | lo even | lo odd], 512 B each
+            const int off = (((s >> 1) * NPT + pt) * 4 + (s & 1)) * 128 + (gg * 16 + i) * 2;   // floats
             *reinterpret_cast<xr_h4*>(ah + off) = h;
-            *reinterpret_cast<xr_h4*>(al + off) = l;
+            *reinterpret_cast<xr_h4*>(ah + off + 256) = l;
         }
     }
     __syncthreads();                               // the resident tile is complete and visible
@@ -166,9 +168,9 @@ __global__ __launch_bounds__((16 / WP + 1) * 64, 1) void gemm_xres_kernel(XresAr
         xr_h8 xh[WP], xl[WP];
 #pragma unroll
         for (int p = 0; p < WP; ++p) {
-            const int o0 = ((2 * t * NPT + wave * WP + p) * 64 + lane) * 2, o1 = o0 + NPT * 128;
-            xh[p] = xr_cat(*reinterpret_cast<const xr_h4*>(ah + o0), *reinterpret_cast<const xr_h4*>(ah + o1));
-            xl[p] = xr_cat(*reinterpret_cast<const xr_h4*>(al + o0), *reinterpret_cast<const xr_h4*>(al + o1));
+            const float* xa = ah + ((t * NPT + wave * WP + p) * 4) * 128 + lane * 2;
+            xh[p] = xr_cat(*reinterpret_cast<const xr_h4*>(xa), *reinterpret_cast<const xr_h4*>(xa + 128));
+            xl[p] = xr_cat(*reinterpret_cast<const xr_h4*>(xa + 256), *reinterpret_cast<const xr_h4*>(xa + 384));
         }
         // groups of CG tiles: their weights in registers, then the three partial products as three sweeps over the
         // 2 x CG independent accumulators (small terms first)
@@ -179,8 +181,8 @@ __global__ __launch_bounds__((16 / WP + 1) * 64, 1) void gemm_xres_kernel(XresAr
 #pragma unroll
             for (int c = 0; c < CG; ++c) {
                 const float* w = wb + (c0 + c) * 512 + lane * 2;
-                bh[c] = xr_cat(*reinterpret_cast<const xr_h4*>(w), *reinterpret_cast<const xr_h4*>(w + 256));
-                bl[c] = xr_cat(*reinterpret_cast<const xr_h4*>(w + 128), *reinterpret_cast<const xr_h4*>(w + 384));
+                bh[c] = xr_cat(*reinterpret_cast<const xr_h4*>(w), *reinterpret_cast<const xr_h4*>(w + 128));
+                bl[c] = xr_cat(*reinterpret_cast<const xr_h4*>(w + 256), *reinterpret_cast<const xr_h4*>(w + 384));
             }
 #pragma unroll
             for (int c = 0; c < CG; ++c)
