@@ -174,7 +174,7 @@ __global__ __launch_bounds__((16 / WP + 1) * 64, 1) void gemm_xres_kernel(XresAr
         }
         // groups of CG tiles: their weights in registers, then the three partial products as three sweeps over the
         // 2 x CG independent accumulators (small terms first)
-        constexpr int CG = WP >= 4 ? (CT % 3 == 0 ? 3 : 2) : (CT % 3 == 0 ? 3 : 4);
+        constexpr int CG = WP >= 4 ? (CT % 3 == 0 ? 3 : 2) : CT;   // WP 2: all weight operands of the stage up front (one LDS round trip)
 #pragma unroll
         for (int c0 = 0; c0 < CT; c0 += CG) {
             xr_h8 bh[CG], bl[CG];
