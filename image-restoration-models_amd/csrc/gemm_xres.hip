@@ -224,9 +224,9 @@ __global__ __launch_bounds__((16 / WP + 1) * 64, 1) void gemm_xres_kernel(XresAr
     }
 }
 
-template <int KT, int CT>
+template <int KT, int CT, int NS = 3>
 static int xres_launch(const XresArgs& a, int B, hipStream_t stream) {
-    constexpr int NS = 3, WP = 2;
+    constexpr int WP = 2;
     const size_t lds = ((size_t)2 * KT * 16 * 128 + (size_t)NS * CT * 512 + 32 * KT) * sizeof(float);
     static bool configured = false;
     if (!configured) {
@@ -252,7 +252,9 @@ int irm_gemm_xres_dispatch(const float* wp, const float* x, long x_bs, float* y,
     switch (a.stages) {
         case 2: return nine ? xres_launch<2, 9>(a, B, stream) : xres_launch<2, 8>(a, B, stream);
         case 4: return nine ? xres_launch<4, 9>(a, B, stream) : xres_launch<4, 8>(a, B, stream);
-        case 6: return nine ? xres_launch<6, 9>(a, B, stream) : xres_launch<6, 8>(a, B, stream);
+        case 6:
+            if (getenv("IRM_XRES_DEEP")) return xres_launch<6, 4, 6>(a, B, stream);      // experiment: 4-tile stages, 6-deep ring
+            return nine ? xres_launch<6, 9>(a, B, stream) : xres_launch<6, 8>(a, B, stream);
         default: return IRM_EINVAL;      // odd stage counts (K = 48): the streaming kernel
     }
 }
