@@ -642,7 +642,7 @@ static int gemm_entry(const float* wp, long w_bs, const float* x, long x_bs, flo
         // weights packed by the caller as fp16 hi/lo pairs: only the ring kernel understands them
         if (!vec || N < 4 || (res && ln_mode != IRM_LN_NONE)) return IRM_EINVAL;
         static const bool no_xres = getenv("IRM_GEMM_NO_XRES") != nullptr;
-        if (K <= 96 && ln_mode != IRM_LN_NONE && !stats_out && !res && !w_bs && !no_xres && B <= 65535 && (long)(N + 127) / 128 <= 2147483647L) {
+        if (K <= 192 && ln_mode != IRM_LN_NONE && !stats_out && !res && !w_bs && !no_xres && B <= 65535 && (long)(N + 127) / 128 <= 2147483647L) {
             const int rc = irm_gemm_xres_dispatch(wp, x, x_bs, y, y_bs, bias, stats, lnw, lnb, ln_mode, act, B, M, K, N, stream);
             if (rc != IRM_EINVAL) return rc;
         }

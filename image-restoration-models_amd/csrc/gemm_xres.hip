@@ -42,13 +42,14 @@ __device__ __forceinline__ xr_h8 xr_cat(xr_h4 a, xr_h4 b) {
 // issues the weight DMAs and waits for them: vmcnt is per wave and retires in order, stores included, so a wave
 // that both stores results and waits for operands sits out the write acknowledgements at every pass boundary;
 // split this way the compute waves never wait on memory, the stage barrier is the only hand-over.
-template <int KT, int CT, int NS, int WP>
-__global__ __launch_bounds__((16 / WP + 1) * 64, 1) void gemm_xres_kernel(XresArgs a) {
-    constexpr int NW = 16 / WP;                    // compute waves, WP pixel tiles each
-    constexpr int NPAR = NW / 4;                   // threads per pixel in the conversion (256 pixels)
+template <int KT, int CT, int NS, int WP, int NPT>
+__global__ __launch_bounds__((NPT / WP + 1) * 64, 1) void gemm_xres_kernel(XresArgs a) {
+    constexpr int NW = NPT / WP;                   // compute waves, WP pixel tiles each
+    constexpr int BN = NPT * 16;                   // pixels per workgroup (256 for K <= 96, 128 / 64 for K <= 192 / 384:
+                                                   // the resident input is 96 KiB in every case)
+    constexpr int NPAR = NW * 64 / BN;             // threads per pixel in the conversion
     constexpr int NQ = 4 * KT / NPAR;              // channel-quad groups per thread
-    constexpr int BN = 256;                        // pixels per workgroup: 16 pixel tiles
-    constexpr int NPT = BN / 16;
+    static_assert(NW * 64 % BN == 0 && (4 * KT) % NPAR == 0, "conversion mapping");
     constexpr int AH = KT * NPT * 128;             // floats of the hi (or lo) half of the resident input
     constexpr int WST = CT * 512;                  // floats per weight stage (CT tiles x 2 KiB)
     constexpr int KP = KT / 2;                     // stage pairs
@@ -111,7 +112,7 @@ __global__ __launch_bounds__((16 / WP + 1) * 64, 1) void gemm_xres_kernel(XresAr
     // resident input: thread = (pixel, half of the channel-quad groups); channel of k-slot (g, j) of stage s
     // is 16 s + 4 j + g (the order the weights are packed in)
     if (!(a.dbg & 1)) {
-        const int px = tid & 255, par = tid >> 8;
+        const int px = tid % BN, par = tid / BN;
         const int n = min(n0 + px, a.N - 1);
         float mean = 0.f, rstd = 1.f;
         if (a.ln_mode != IRM_LN_NONE) {
@@ -224,22 +225,22 @@ __global__ __launch_bounds__((16 / WP + 1) * 64, 1) void gemm_xres_kernel(XresAr
     }
 }
 
-template <int KT, int CT, int NS = 3>
+template <int KT, int CT, int NS = 3, int NPT = 16, int WP = 2>
 static int xres_launch(const XresArgs& a, int B, hipStream_t stream) {
-    constexpr int WP = 2;
-    const size_t lds = ((size_t)2 * KT * 16 * 128 + (size_t)NS * CT * 512 + 32 * KT) * sizeof(float);
+    const size_t lds = ((size_t)2 * KT * NPT * 128 + (size_t)NS * CT * 512 + 32 * KT) * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xres_kernel<KT, CT, NS, WP>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xres_kernel<KT, CT, NS, WP, NPT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return IRM_ELAUNCH;
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_xres_kernel<KT, CT, NS, WP>), dim3((a.N + 255) / 256, 1, B), dim3((16 / WP + 1) * 64), lds, stream, a);
+    hipLaunchKernelGGL((gemm_xres_kernel<KT, CT, NS, WP, NPT>), dim3((a.N + NPT * 16 - 1) / (NPT * 16), 1, B),
+                       dim3((NPT / WP + 1) * 64), lds, stream, a);
     return irm_launch_status();
 }
 
-// called by irm_gemm1x1_f16x3_f32 (gemm_pw.hip) for K <= 96; returns IRM_EINVAL for shapes it does not cover
+// called by irm_gemm1x1_f16x3_f32 (gemm_pw.hip) for K <= 384; returns IRM_EINVAL for shapes it does not cover
 int irm_gemm_xres_dispatch(const float* wp, const float* x, long x_bs, float* y, long y_bs, const float* bias,
                            const float* stats, const float* lnw, const float* lnb, int ln_mode, int act, int B, int M,
                            int K, int N, hipStream_t stream) {
@@ -255,6 +256,10 @@ int irm_gemm_xres_dispatch(const float* wp, const float* x, long x_bs, float* y,
         case 6:
             if (getenv("IRM_XRES_DEEP")) return xres_launch<6, 4, 6>(a, B, stream);      // experiment: 4-tile stages, 6-deep ring
             return nine ? xres_launch<6, 9>(a, B, stream) : xres_launch<6, 8>(a, B, stream);
-        default: return IRM_EINVAL;      // odd stage counts (K = 48): the streaming kernel
+        case 12:
+            if (M < 512) return IRM_EINVAL;      // few output tiles per converted input: the streaming kernel is faster
+            return nine ? xres_launch<12, 9, 3, 8, 2>(a, B, stream) : xres_launch<12, 8, 3, 8, 2>(a, B, stream);
+        default: return IRM_EINVAL;      // odd stage counts (K = 48), K = 384 (64-pixel tiles: measured slower than
+                                         // streaming) and other sizes: the streaming kernel
     }
 }
