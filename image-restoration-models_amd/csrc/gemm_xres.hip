@@ -1,10 +1,10 @@
-// LayerNorm + 1x1 conv for K <= 96 input channels as an fp32 emulation on the fp16 matrix cores, with the
-// INPUT tile resident: the workgroup's 128 pixels x K channels are read once, normalised, split into fp16
-// hi + lo (x = hi + lo up to 2^-22 |x|) and parked in LDS in MFMA A-operand order (4 K per channel-16 block
-// and pixel-16 block); after that every output-channel pass is pure matrix work - the split weights (packed
-// by the host, L2 resident) stream through a small LDS-DMA ring, three 16x16x16 MFMAs (lo*hi, hi*lo, hi*hi)
-// per tile accumulate in fp32.  The streaming kernel (gemm_pw.hip, F16) re-reads and re-splits the input for
-// every pass; here the passes cost no VALU and no input traffic.
+// LayerNorm + 1x1 conv for K <= 192 input channels as an fp32 emulation on the fp16 matrix cores, with the
+// INPUT tile resident: the workgroup's 256 (K <= 96) or 128 (K <= 192) pixels x K channels are read once,
+// normalised, split into fp16 hi + lo (x = hi + lo up to 2^-22 |x|) and parked in LDS in MFMA A-operand order
+// (96 KiB); after that every output-channel pass is pure matrix work - the split weights (packed by the host,
+// L2 resident) stream through a small LDS-DMA ring, three v_mfma_f32_16x16x32_f16 (lo*hi, hi*lo, hi*hi) per
+// tile and 32 input channels accumulate in fp32.  The streaming kernel (gemm_pw.hip, F16) re-reads and
+// re-splits the input for every pass; here the passes cost no VALU and no input traffic.
 //   replaces: LayerNorm (restormer.py:25-70) + Attention.qkv / FeedForward.project_in (restormer.py:82,105)
 #include "irm_common.h"
 #include <stdlib.h>

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
             else acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[i], 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(acc[i]));
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+a"(acc[i]));
     }
     float s = 0;
     for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
