@@ -187,7 +187,7 @@ def mdta_plan(B: int, C: int, heads: int, N: int):
     # the LDS-DMA ring kernel (c = 48 / 96, N % 64 == 0) keeps the whole c x c Gram in one workgroup
     nsub = 1 if (c in (48, 96) and N % 64 == 0) else (c // (16 * sb)) ** 2
     per_wg = 1 if nsub == 1 and c in (48, 96) and N % 64 == 0 else 4        # units per workgroup
-    tb = int(os.environ.get("IRM_GRAM_BLOCKS", 0)) or (2 * target_blocks() if per_wg == 1 else target_blocks())
+    tb = int(os.environ.get("IRM_GRAM_BLOCKS", 0)) or target_blocks()
     chunk = -(-(N * B * heads * nsub) // (per_wg * tb))
     chunk = min(max(-(-chunk // 64) * 64, 256), 4096)
     return chunk, -(-N // chunk), c * c + 2 * c
