@@ -29,6 +29,8 @@ SIGNATURES = {
     "irm_dwconv3x3_gate_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "irm_dwgemm_f32": [_P, _L, _P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _F, _P],
     "irm_dwgemm_f16x3_f32": [_P, _L, _P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _F, _P],
+    "irm_gdfn_fused_f16x3_f32": [_P, _P, _P, _P, _L, _P, _L, _I, _F, _F, _F, _I, _I, _I, _I, _I, _P],
+    "irm_qkv_dw_fused_f16x3_f32": [_P, _P, _L, _P, _L, _I, _F, _F, _I, _I, _I, _I, _I, _P],
     "irm_mdta_gram_f32": [_P, _L, _P, _I, _I, _I, _I, _I, _P],
     "irm_mdta_finalize_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "irm_mdta_finalize_f16x3_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -148,6 +150,115 @@ def pack_dw_table(w9: torch.Tensor, bias, K: int, gate: bool) -> torch.Tensor:
         if bias is not None:
             t[:K, 19] = bias[K:2 * K].float()
     return t.repeat_interleave(2, dim=1).contiguous().view(-1)
+
+
+def _pow2_scale(t: torch.Tensor, target_exp: int = 13) -> float:
+    """Power of two s with max|t| * s in [2^target_exp, 2^(target_exp+1)): the fp16 hi part then keeps 11 bits and
+    the lo part stays a NORMAL fp16 number for every element down to 2^-17 of the largest (range guard of the
+    hi/lo split, any weight magnitude)."""
+    m = float(t.abs().max())
+    if not (m > 0.0) or m != m or m == float("inf"):
+        return 1.0
+    import math
+    return 2.0 ** (target_exp - math.floor(math.log2(m)))
+
+
+def _split_h(t32: torch.Tensor):
+    hi = t32.half()
+    lo = (t32 - hi.float()).half()
+    return hi, lo
+
+
+def pack_gdfn_fused(pin_w, pin_b, dw_w, dw_b, pout_w, lnw, lnb):
+    """Operands of irm_gdfn_fused_f16x3_f32 (include/irm_hip.h) from the reference's parameters
+    (FeedForward.project_in / dwconv / project_out and norm2, restormer.py:76-93, 141):
+    returns (rec, w2, inv_s1, inv_s2).  The LayerNorm weight is folded into project_in (W diag(w)) and the
+    LayerNorm bias into its bias (W b) in float64, so the kernel normalises only."""
+    dev = pin_w.device
+    pin = pin_w.detach().reshape(pin_w.shape[0], -1).double().cpu()
+    pout = pout_w.detach().reshape(pout_w.shape[0], -1).double().cpu()
+    C, hid = pin.shape[1], pout.shape[1]
+    assert pin.shape[0] == 2 * hid and pout.shape[0] == C
+    S, KS, CT = (hid + 15) // 16, (C + 31) // 32, (C + 15) // 16
+    if CT == 5:
+        CT = 6
+    SS = (S + 1) // 2
+    w1 = pin * lnw.detach().double().cpu()[None, :]
+    b1 = torch.zeros(2 * hid, dtype=torch.float64)
+    if pin_b is not None:
+        b1 += pin_b.detach().double().cpu()
+    if lnb is not None:
+        b1 += pin @ lnb.detach().double().cpu()
+    # ---- project_in: [half][16 S][32 KS] zero padded, scaled, split
+    s1 = _pow2_scale(w1)
+    w1f = torch.zeros(2, 16 * S, 32 * KS, dtype=torch.float32)
+    w1f[:, :hid, :C] = (w1.float() * s1).view(2, hid, C)
+    hi, lo = _split_h(w1f)
+
+    def arr1(t):      # [hct][S][16 m][KS][4 g][8 j] -> [S][hct][KS][g][m][j]
+        return t.view(2, S, 16, KS, 4, 8).permute(1, 0, 3, 4, 2, 5)
+    w1pk = torch.stack([arr1(hi), arr1(lo)], dim=3).contiguous()          # [S][hct][KS][2][g][m][8]
+    w1pk = w1pk.view(S, -1).view(torch.float32)                             # [S][KS*1024]
+    # ---- taps + bias of the depth-wise conv, bias of project_in
+    dwf = torch.zeros(2, 16 * S, 10, dtype=torch.float32)
+    dwf[:, :hid, :9] = dw_w.detach().reshape(2 * hid, 9).float().cpu().view(2, hid, 9)
+    if dw_b is not None:
+        dwf[:, :hid, 9] = dw_b.detach().float().cpu().view(2, hid)
+    coef = dwf.view(2, S, 16, 10).permute(1, 3, 0, 2).contiguous().view(S, 320)     # [S][t][hct*16+m]
+    b1f = torch.zeros(2, 16 * S, dtype=torch.float32)
+    b1f[:, :hid] = b1.float().view(2, hid)
+    bias1 = b1f.view(2, S, 16).permute(1, 0, 2).contiguous().view(S, 32)
+    rec = torch.zeros(S + 1, KS * 1024 + 512, dtype=torch.float32)
+    rec[:S, :KS * 1024] = w1pk
+    rec[1:, KS * 1024:KS * 1024 + 320] = coef
+    rec[:S, KS * 1024 + 320:KS * 1024 + 352] = bias1
+    # ---- project_out: k-slot (g, j) of super-stage T <-> gate channel 32 T + 16 (j >> 2) + 4 g + (j & 3)
+    s2 = _pow2_scale(pout)
+    w2f = torch.zeros(16 * CT, 32 * SS, dtype=torch.float32)
+    w2f[:C, :hid] = pout.float() * s2
+    h2, l2 = _split_h(w2f)
+
+    def arr2(t):      # [CT][16 m][SS][2 jh][4 g][4 jl] -> [SS][CT][g][m][jh][jl]
+        return t.view(CT, 16, SS, 2, 4, 4).permute(2, 0, 4, 1, 3, 5)
+    w2pk = torch.stack([arr2(h2), arr2(l2)], dim=2).contiguous()           # [SS][CT][2][g][m][8]
+    w2pk = w2pk.view(-1).view(torch.float32)
+    return rec.view(-1).to(dev), w2pk.to(dev), 1.0 / (16.0 * s1), 16.0 / s2
+
+
+def pack_qkv_fused(qkv_w, qkv_b, dw_w, dw_b, lnw, lnb):
+    """Operands of irm_qkv_dw_fused_f16x3_f32 from Attention.qkv / qkv_dwconv and norm1 (restormer.py:105-106, 140):
+    returns (rec, inv_s1).  Stage s covers output channels 32 s .. 32 s + 31; LayerNorm weight / bias folded as in
+    pack_gdfn_fused."""
+    dev = qkv_w.device
+    w = qkv_w.detach().reshape(qkv_w.shape[0], -1).double().cpu()
+    M, C = w.shape
+    S, KS = (M + 31) // 32, (C + 31) // 32
+    w1 = w * lnw.detach().double().cpu()[None, :]
+    b1 = torch.zeros(M, dtype=torch.float64)
+    if qkv_b is not None:
+        b1 += qkv_b.detach().double().cpu()
+    if lnb is not None:
+        b1 += w @ lnb.detach().double().cpu()
+    s1 = _pow2_scale(w1)
+    w1f = torch.zeros(32 * S, 32 * KS, dtype=torch.float32)
+    w1f[:M, :C] = w1.float() * s1
+    hi, lo = _split_h(w1f)
+
+    def arr1(t):      # [S][hct][16 m][KS][4 g][8 j] -> [S][hct][KS][g][m][j]
+        return t.view(S, 2, 16, KS, 4, 8).permute(0, 1, 3, 4, 2, 5)
+    w1pk = torch.stack([arr1(hi), arr1(lo)], dim=3).contiguous().view(S, -1).view(torch.float32)
+    dwf = torch.zeros(32 * S, 10, dtype=torch.float32)
+    dwf[:M, :9] = dw_w.detach().reshape(M, 9).float().cpu()
+    if dw_b is not None:
+        dwf[:M, 9] = dw_b.detach().float().cpu()
+    coef = dwf.view(S, 32, 10).permute(0, 2, 1).contiguous().view(S, 320)
+    b1f = torch.zeros(32 * S, dtype=torch.float32)
+    b1f[:M] = b1.float()
+    rec = torch.zeros(S + 1, KS * 1024 + 512, dtype=torch.float32)
+    rec[:S, :KS * 1024] = w1pk
+    rec[1:, KS * 1024:KS * 1024 + 320] = coef
+    rec[:S, KS * 1024 + 320:KS * 1024 + 352] = b1f.view(S, 32)
+    return rec.view(-1).to(dev), 1.0 / (16.0 * s1)
 
 
 def deconv_as_conv_weight(w: torch.Tensor) -> torch.Tensor:

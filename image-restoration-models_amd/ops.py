@@ -180,6 +180,37 @@ def dwgemm(wp, dwp, x, y, M: int, K: int, *, gate: bool, res=None, bias=None, w_
             _hip.ptr(stats_out), float(eps), tag=f"M{M} K{K} {H}x{W} B{B} gate{int(bool(gate))}")
 
 
+def can_fuse_gdfn(C: int, W: int) -> bool:
+    """irm_gdfn_fused_f16x3_f32 keeps the input tile of all C channels in registers."""
+    return C <= 96 and C % 16 == 0 and W % 4 == 0
+
+
+def gdfn_fused(pk, x, y, C: int, hid: int, *, ln_mode, bias=None, eps: float = 1e-5):
+    """y = x + project_out(gelu(dw(h)[:hid]) * dw(h)[hid:]), h = project_in(LN(x)) in one kernel (y is not x);
+    pk = _hip.pack_gdfn_fused(...)."""
+    _chk(x, "x"), _chk(y, "y")
+    B, _, H, W = x.shape
+    assert x.data_ptr() != y.data_ptr() and x.shape[1] >= C and y.shape[1] >= C
+    rec, w2, inv_s1, inv_s2 = pk
+    N = H * W
+    flops = B * N * (2.0 * 2 * hid * C + 36.0 * hid + 2.0 * hid * C)
+    _launch("gdfn_fused", flops, 4.0 * B * N * 2 * C, "irm_gdfn_fused_f16x3_f32", _hip.ptr(rec), _hip.ptr(w2),
+            _hip.ptr(bias), _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y), int(ln_mode), float(eps), float(inv_s1),
+            float(inv_s2), B, C, hid, H, W, tag=f"C{C} hid{hid} {H}x{W} B{B}")
+
+
+def qkv_dw_fused(pk, x, y, C: int, M: int, *, ln_mode, eps: float = 1e-5):
+    """y[:, :M] = dw3x3(W @ LN(x) + b) in one kernel (y is not x); pk = _hip.pack_qkv_fused(...)."""
+    _chk(x, "x"), _chk(y, "y")
+    B, _, H, W = x.shape
+    assert x.data_ptr() != y.data_ptr() and x.shape[1] >= C and y.shape[1] >= M
+    rec, inv_s1 = pk
+    N = H * W
+    _launch("qkv_dw_fused", B * N * (2.0 * M * C + 18.0 * M), 4.0 * B * N * (C + M), "irm_qkv_dw_fused_f16x3_f32",
+            _hip.ptr(rec), _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y), int(ln_mode), float(eps), float(inv_s1), B, C, M,
+            H, W, tag=f"C{C} M{M} {H}x{W} B{B}")
+
+
 def mdta_plan(B: int, C: int, heads: int, N: int):
     """(chunk, nchunk, record size) of the Gram pass for this problem size."""
     c = C // heads

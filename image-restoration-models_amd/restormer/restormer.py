@@ -191,6 +191,13 @@ class Restormer(nn.Module):
                     pk[name].update(qkv_s=_hip.pack_gemm_weight_split(a.qkv.weight),
                                     pin_s=_hip.pack_gemm_weight_split(ff.project_in.weight),
                                     pout_s=_hip.pack_gemm_weight_split(ff.project_out.weight))
+                if self._split and ops.can_fuse_gdfn(m.dim, 4):
+                    # whole-branch kernels (fused_block.hip): LN + qkv + dwconv, and the complete GDFN
+                    pk[name].update(
+                        qkv_f=_hip.pack_qkv_fused(a.qkv.weight, a.qkv.bias, a.qkv_dwconv.weight, a.qkv_dwconv.bias,
+                                                  m.norm1.w, m.norm1.b),
+                        gdfn_f=_hip.pack_gdfn_fused(ff.project_in.weight, ff.project_in.bias, ff.dwconv.weight,
+                                                    ff.dwconv.bias, ff.project_out.weight, m.norm2.w, m.norm2.b))
                 if ops.can_fuse_dw(m.dim, 4):
                     # depth-wise coefficient tables of the fused dw + 1x1 kernel (irm_dwgemm_f32)
                     c, dw, dwb = m.dim, a.qkv_dwconv.weight.reshape(-1, 9), a.qkv_dwconv.bias
@@ -293,6 +300,32 @@ class Restormer(nn.Module):
                         stats_out=stats if emit else None, split=split)
         return emit
 
+    def _block_fused(self, blk: TransformerBlock, w: dict, x: torch.Tensor, alt: torch.Tensor) -> torch.Tensor:
+        """One TransformerBlock on the whole-branch kernels (C <= 96): x -> alt, returns alt.
+
+        qkv_dw_fused (LN1 + qkv + depth-wise, restormer.py:105-106) -> Gram + softmax + fold (:118-129) ->
+        1x1 with the folded per-image matrix on v, + x in place (:131, 147) -> gdfn_fused (LN2 + GDFN + x, :148)
+        into alt: neighbouring tiles read each other's halo of x, so the last step cannot run in place."""
+        B, C, H, W = x.shape
+        N = H * W
+        dev = x.device
+        heads, hid = blk.attn.num_heads, blk.ffn.hidden
+        qkv = self._buf("scratch_a", B * 3 * C * N, dev).view(B, 3 * C, H, W)
+        ops.qkv_dw_fused(w["qkv_f"], x, qkv, C, 3 * C, ln_mode=blk.norm1.mode)
+        _, nchunk, rec = ops.mdta_plan(B, C, heads, N)
+        part = self._buf("gram_part", B * heads * nchunk * rec, dev)
+        gsum = self._buf("gram_sum", B * heads * rec, dev)
+        mfold_n = ops.mfold_numel(C)
+        ws = self._ws
+        mfold = ws.get(("mfold", C, B))
+        if mfold is None or mfold.device != dev:
+            mfold = torch.zeros(B * mfold_n, dtype=torch.float32, device=dev)
+            ws[("mfold", C, B)] = mfold
+        ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=True)
+        ops.gemm1x1(mfold, qkv[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n, split=True)
+        ops.gdfn_fused(w["gdfn_f"], x, alt, C, hid, ln_mode=blk.norm2.mode, bias=w["pout_b"])
+        return alt
+
     @staticmethod
     def _c3(wp, x, y, ci, co, h, w, **kw):
         assert x.shape[2] == h and x.shape[3] == w
@@ -304,6 +337,18 @@ class Restormer(nn.Module):
 
     def _run_stage(self, name, pk, x, have_stats=False):
         blocks = getattr(self, name)
+        B, C, H, W = x.shape
+        if (len(blocks) and "gdfn_f" in pk[f"{name}.0"] and ops.can_fuse_gdfn(C, W) and (H * W) % 4 == 0
+                and not os.environ.get("IRM_NO_FUSE_BLOCK")):
+            cur, alt = x, self._buf(f"alt_{C}", B * C * H * W, x.device).view(B, C, H, W)
+            for i, blk in enumerate(blocks):
+                out = self._block_fused(blk, pk[f"{name}.{i}"], cur, alt)
+                cur, alt = out, cur
+            if cur is not x:                           # odd number of blocks: the stage result belongs in x
+                x.copy_(cur)
+                if ops.TIMER is not None:
+                    ops.TIMER.break_chain()
+            return False
         for i, blk in enumerate(blocks):
             have_stats = self._block(blk, pk[f"{name}.{i}"], x, have_stats, want_stats=i + 1 < len(blocks))
         return have_stats

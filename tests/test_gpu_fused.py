@@ -1,0 +1,135 @@
+"""GPU parity tests of the whole-branch fused kernels (fused_block.hip) through the C ABI against float64
+references of the same chain of reference ops (restormer.py:25-70, 76-93, 148).
+
+Bar: <= 2e-5 x max(1, |ref|max) vs float64 (fp32-level: a plain fp32 torch chain measures 1e-6..6e-6 here, the fused kernels 1e-6..8e-6, tools/err_fused.py) (the path's budget is 1e-3 max-abs, BASELINE.json north_star),
+and not worse than 2x the un-fused exact-f32 chain on the same inputs where that is compared."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from irm_amd import _hip, ops, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def rnd(name, shape, lo=-1.0, hi=1.0):
+    return synth.uniform(321, name, shape, lo, hi)
+
+
+def gdfn_ref(x, lnw, lnb, ln_mode, pin_w, pin_b, dw_w, dw_b, pout_w, pout_b, eps=1e-5):
+    """float64: x + project_out(gelu(dw(h)[:hid]) * dw(h)[hid:]), h = project_in(LN(x))."""
+    xd = x.double()
+    mu = xd.mean(1, keepdim=True)
+    var = xd.var(1, unbiased=False, keepdim=True)
+    if ln_mode == _hip.LN_WITHBIAS:
+        xn = (xd - mu) / torch.sqrt(var + eps) * lnw.double()[None, :, None, None] + lnb.double()[None, :, None, None]
+    else:
+        xn = xd / torch.sqrt(var + eps) * lnw.double()[None, :, None, None]
+    hid = pout_w.shape[1]
+    h = F.conv2d(xn, pin_w.double()[:, :, None, None], None if pin_b is None else pin_b.double())
+    h = F.conv2d(h, dw_w.double().view(2 * hid, 1, 3, 3), None if dw_b is None else dw_b.double(), padding=1,
+                 groups=2 * hid)
+    g = F.gelu(h[:, :hid]) * h[:, hid:]
+    return xd + F.conv2d(g, pout_w.double()[:, :, None, None], None if pout_b is None else pout_b.double())
+
+
+GDFN_CASES = [
+    # C, hid, H, W, B, ln_mode, bias, scale of the weights
+    (96, 255, 16, 64, 1, 1, False, 0.3),
+    (96, 255, 24, 40, 2, 2, True, 0.3),
+    (48, 127, 16, 32, 2, 1, True, 0.3),
+    (48, 127, 20, 36, 1, 2, False, 0.3),
+    (96, 255, 8, 8, 1, 1, False, 0.3),
+    (32, 85, 12, 20, 1, 1, True, 0.3),
+    (64, 170, 8, 44, 2, 2, False, 0.3),
+    (96, 255, 40, 72, 1, 1, True, 3.0),          # large weights: the power-of-two operand scales adapt
+    (96, 250, 16, 32, 1, 1, False, 1e-3),        # tiny weights
+]
+
+
+@pytest.mark.parametrize("C,hid,H,W,B,ln,bias,ws", GDFN_CASES)
+def test_gdfn_fused(dev, C, hid, H, W, B, ln, bias, ws):
+    tag = f"f{C}_{hid}_{H}_{W}_{B}_{ln}"
+    big = rnd(tag + "x", (B, C + 3, H, W), -1.5, 2.0)
+    lnw = rnd(tag + "lw", (C,), 0.5, 1.5)
+    lnb = rnd(tag + "lb", (C,), -0.2, 0.2) if ln == 1 else None
+    pin_w = rnd(tag + "pi", (2 * hid, C), -ws, ws)
+    pout_w = rnd(tag + "po", (C, hid), -ws, ws)
+    dw_w = rnd(tag + "dw", (2 * hid, 9), -0.4, 0.4)
+    pin_b = rnd(tag + "pib", (2 * hid,), -0.3, 0.3) if bias else None
+    dw_b = rnd(tag + "dwb", (2 * hid,), -0.3, 0.3) if bias else None
+    pout_b = rnd(tag + "pob", (C,), -0.3, 0.3) if bias else None
+    x = big[:, 1:1 + C]
+    ref = gdfn_ref(x, lnw, lnb, ln, pin_w, pin_b, dw_w, dw_b, pout_w, pout_b)
+    pk = _hip.pack_gdfn_fused(pin_w.to(dev), pin_b, dw_w, dw_b, pout_w, lnw, lnb)
+    xb = big.to(dev)
+    yb = torch.full((B, C + 2, H, W), 7.0, device=dev)
+    ops.gdfn_fused(pk, xb[:, 1:1 + C], yb[:, 2:2 + C], C, hid, ln_mode=ln,
+                   bias=None if pout_b is None else pout_b.to(dev))
+    y = yb.cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((y[:, 2:2 + C].double() - ref).abs().max())
+    assert err <= TOL * scale, (err, scale)
+    assert torch.all(y[:, :2] == 7.0), "wrote outside its channel slice"
+    assert torch.equal(xb.cpu(), big), "input modified"
+
+
+def test_gdfn_fused_deterministic(dev):
+    C, hid, H, W = 96, 255, 32, 64
+    x = rnd("detx", (2, C, H, W), -2, 2).to(dev)
+    pk = _hip.pack_gdfn_fused(rnd("d1", (2 * hid, C), -.3, .3).to(dev), None, rnd("d2", (2 * hid, 9), -.4, .4), None,
+                              rnd("d3", (C, hid), -.3, .3), rnd("d4", (C,), .5, 1.5), rnd("d5", (C,), -.2, .2))
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    ops.gdfn_fused(pk, x, y1, C, hid, ln_mode=1)
+    ops.gdfn_fused(pk, x, y2, C, hid, ln_mode=1)
+    assert torch.equal(y1, y2)
+
+
+def qkv_ref(x, lnw, lnb, ln_mode, w, b, dw_w, dw_b, eps=1e-5):
+    xd = x.double()
+    mu = xd.mean(1, keepdim=True)
+    var = xd.var(1, unbiased=False, keepdim=True)
+    if ln_mode == _hip.LN_WITHBIAS:
+        xn = (xd - mu) / torch.sqrt(var + eps) * lnw.double()[None, :, None, None] + lnb.double()[None, :, None, None]
+    else:
+        xn = xd / torch.sqrt(var + eps) * lnw.double()[None, :, None, None]
+    M = w.shape[0]
+    h = F.conv2d(xn, w.double()[:, :, None, None], None if b is None else b.double())
+    return F.conv2d(h, dw_w.double().view(M, 1, 3, 3), None if dw_b is None else dw_b.double(), padding=1, groups=M)
+
+
+QKV_CASES = [
+    # C, H, W, B, ln_mode, bias
+    (96, 16, 64, 1, 1, False),
+    (96, 24, 40, 2, 2, True),
+    (48, 16, 32, 2, 1, True),          # M = 144: the last stage is half empty
+    (48, 20, 36, 1, 2, False),
+    (96, 8, 8, 1, 1, False),
+    (32, 12, 20, 1, 1, True),
+    (64, 40, 72, 1, 2, False),
+]
+
+
+@pytest.mark.parametrize("C,H,W,B,ln,bias", QKV_CASES)
+def test_qkv_dw_fused(dev, C, H, W, B, ln, bias):
+    tag = f"q{C}_{H}_{W}_{B}_{ln}"
+    M = 3 * C
+    big = rnd(tag + "x", (B, C + 3, H, W), -1.5, 2.0)
+    lnw = rnd(tag + "lw", (C,), 0.5, 1.5)
+    lnb = rnd(tag + "lb", (C,), -0.2, 0.2) if ln == 1 else None
+    w = rnd(tag + "w", (M, C), -0.3, 0.3)
+    dw_w = rnd(tag + "dw", (M, 9), -0.4, 0.4)
+    wb = rnd(tag + "wb", (M,), -0.3, 0.3) if bias else None
+    dw_b = rnd(tag + "dwb", (M,), -0.3, 0.3) if bias else None
+    x = big[:, 1:1 + C]
+    ref = qkv_ref(x, lnw, lnb, ln, w, wb, dw_w, dw_b)
+    pk = _hip.pack_qkv_fused(w.to(dev), wb, dw_w, dw_b, lnw, lnb)
+    xb = big.to(dev)
+    yb = torch.full((B, M + 2, H, W), 7.0, device=dev)
+    ops.qkv_dw_fused(pk, xb[:, 1:1 + C], yb[:, 1:1 + M], C, M, ln_mode=ln)
+    y = yb.cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((y[:, 1:1 + M].double() - ref).abs().max())
+    assert err <= TOL * scale, (err, scale)
+    assert torch.all(y[:, 0] == 7.0) and torch.all(y[:, M + 1] == 7.0), "wrote outside its channel slice"
