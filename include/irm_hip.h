@@ -125,6 +125,35 @@ int irm_dwgemm_f16x3_f32(const float* wp_split, long w_bs, const float* dwp, con
                          const float* res, long r_bs, const float* bias, int gate, int B, int M, int K, int H, int W,
                          float* stats_out, float eps, irm_stream_t stream);
 
+/* Whole-branch kernels for C <= 96 (fused_block.hip): the input tile (8 x 32 pixels + 1-pixel halo, all C channels)
+ * is read once, normalised in registers (LayerNorm statistics computed in the kernel) and kept there as fp16 hi/lo
+ * MFMA operands; the wide intermediate (2*hid or 3*C channels) exists only in LDS, 32 channels at a time.  All 1x1
+ * convs are the fp32 emulation of irm_gemm1x1_f16x3_f32 (three fp16 MFMAs on hi/lo splits, fp32 accumulate).
+ * x != y (tiles read their neighbours' halo); W % 4 == 0; channel / pixel axes dense, batch strides free.
+ *
+ * irm_gdfn_fused_f16x3_f32:  y = x + project_out(gelu_erf(dw(h)[:hid]) * dw(h)[hid:]) + bias2,  h = project_in(LN(x)) + b
+ *   replaces norm2 + FeedForward + residual (restormer.py:25-70, 76-93, 148); ln_mode 1 = WithBias, 2 = BiasFree.
+ * Operands packed by the host (Python: _hip.pack_gdfn_fused), KS = ceil(C/32), S = ceil(hid/16), CT = ceil(C/16):
+ *   rec [S+1][KS*1024 + 512] floats, record i =
+ *     [2 tiles][KS][hi|lo][64 lanes][8 halves]: W1' * s1 split into fp16 hi + lo, W1' = project_in.weight * diag(ln.weight);
+ *        tile 0 = gate channels 16 i + m, tile 1 = channels hid + 16 i + m; lane = 16 g + m, half j -> input
+ *        channel 32 ks + 8 g + j (zero beyond C / hid; record S: zeros)
+ *     [10][32] floats: the 9 depth-wise taps + bias of the channels of stage i - 1 (tile 0 | tile 1) (record 0: zeros)
+ *     [32] floats: bias of h for stage i = project_in.bias + project_in.weight @ ln.bias;  pad to 512
+ *   w2 [ceil(S/2)][CT][hi|lo][64 lanes][8 halves]: project_out.weight * s2 split; lane = 16 g + co, half j of
+ *        super-stage T -> gate channel 32 T + 16 (j >> 2) + 4 g + (j & 3)
+ *   inv_s1 = 1 / (16 s1), inv_s2 = 16 / s2 with power-of-two s1, s2 chosen so that max |W| * s lies in [2^13, 2^14)
+ *   (the fp16 lo parts stay normal numbers for weights of any magnitude).
+ *
+ * irm_qkv_dw_fused_f16x3_f32:  y[:, :M] = dw3x3(W LN(x) + b)  (M = 3C: norm1 + Attention.qkv + qkv_dwconv,
+ *   restormer.py:105-106, 116).  rec as above with S = ceil(M/32) and tile t of record i = output channels
+ *   32 i + 16 t + m (Python: _hip.pack_qkv_fused). */
+int irm_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const float* bias2, const float* x, long x_bs, float* y,
+                             long y_bs, int ln_mode, float eps, float inv_s1, float inv_s2, int B, int C, int hid, int H,
+                             int W, irm_stream_t stream);
+int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode, float eps,
+                               float inv_s1, int B, int C, int M, int H, int W, irm_stream_t stream);
+
 /* MDTA pass 1: per-chunk partial Gram matrices and squared norms.
  * qkv: [B][3C][N] (after qkv_dwconv; q rows [0,C), k rows [C,2C)).
  * part: workspace [B][heads][ceil(N/chunk)][c*c + 2c] floats, c = C/heads,
