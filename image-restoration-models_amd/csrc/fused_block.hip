@@ -20,19 +20,14 @@
 // matrix and vector pipes overlap.
 #include "irm_common.h"
 #include <utility>
+#ifdef FB_STAMP
+#include <stdlib.h>
+#endif
 
 typedef _Float16 fb_h8 __attribute__((ext_vector_type(8)));
 typedef float fb_v2 __attribute__((ext_vector_type(2)));
 
-#ifndef FB_ABL
-#define FB_ABL 0      // timing-only ablations (tools/build_variant.sh): never set in the product build
-#endif
-#ifndef FB_STAGGER
-#define FB_STAGGER 1    // x 16 steps of ~3.9 us
-#endif
-#ifndef FB_INTERLEAVE
-#define FB_INTERLEAVE 3
-#endif
+#define FB_INTERLEAVE 3      // plain VALU instructions scheduled behind each MFMA of a GEMM unit
 #define FB_TH 8
 #define FB_TW 32
 #define FB_HC (FB_TW + 2)                 // halo columns
@@ -49,7 +44,11 @@ struct FusedArgs {
     const float* bias2;                   // [C] or null
     int C, H, W, S, M;                    // S = ceil(hid / 16) (GATE) or ceil(M / 32) stages; M = output channels (!GATE)
     int ln_mode; float eps, inv_s1, inv_s2;
-    int tiles_x, tiles;
+    int tiles_x, tiles;                   // tiles per image
+    int items, gpx;                       // B * tiles; workgroups per XCD
+#ifdef FB_STAMP
+    unsigned long long* dbg;
+#endif
 };
 
 __device__ __forceinline__ fb_v2 fb_gelu2(fb_v2 x) {
@@ -117,6 +116,14 @@ template <int N, class F>
 __device__ __forceinline__ void fb_for(F&& f) { fb_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // NP pieces of 1 KiB, piece i issued by wave i % 8 (LDS destination = wave-uniform base + lane * 16)
+#ifdef FB_STAMP
+// diagnostic build (tools/build_variant.sh -DFB_STAMP): phase cycle sums of wave 0 of every workgroup -> a.dbg; never in the product
+#define FB_T(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                     stamp[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define FB_T(i) do { } while (0)
+#endif
+
 template <int NP>
 __device__ __forceinline__ void fb_dma(const float* src, float* dst, int wave, int lane) {
 #pragma unroll
@@ -131,6 +138,10 @@ __device__ __forceinline__ void fb_dma(const float* src, float* dst, int wave, i
 // GATE: the GDFN branch (header).  !GATE: the front half of MDTA - y[3C] = dw3x3(qkv(LN(x))) (restormer.py:105-106,
 // 116-117 + norm1), stages of 32 output channels, the stencil outputs go straight to HBM (one iteration late, so that
 // the iteration-end vmcnt(0) never waits for a fresh store).
+//
+// Persistent: one workgroup per CU walks its share of the (image, tile) items; the raw input of the NEXT item is
+// requested during the last stage of the current one (the operand registers of the finished GEMM are free by then),
+// so its HBM latency and the epilogue stores overlap compute, and nothing is paid per tile for workgroup launch.
 template <int KS, int CT, bool GATE>
 __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
     constexpr int W1F = KS * 1024;                 // floats of project_in weights per record (2 tiles x KS x hi/lo x 1 KiB)
@@ -145,338 +156,412 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
     float* slots = smem;
     float* w2a = smem + W2_OFF / 4;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, r = lane & 15;
-    const int b = blockIdx.y;
-    const int per = (a.tiles + 7) >> 3;
-    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);     // runs of tiles on one XCD
-    if (tile >= a.tiles) return;
-    const int ty0 = (tile / a.tiles_x) * FB_TH, tx0 = (tile % a.tiles_x) * FB_TW;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const long plane = (long)a.H * a.W;
-    const float* X = a.X + (long)b * a.x_bs;
-    const int S = (FB_ABL & 32) ? 1 : a.S;
+    const int S = a.S;
+    // item order: workgroups with equal blockIdx % 8 share an XCD (round-robin placement, speed only): they walk one
+    // contiguous eighth of the items, 'a.gpx' neighbours per round
+    const int per = (a.items + 7) >> 3;
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    auto item_of = [&](int round) { const int i = round * a.gpx + pos; return i < per ? xcd * per + i : a.items; };
 
-#if FB_STAGGER
-    // The first workgroup of every CU starts late by a different fraction of a tile period: all tiles take the same
-    // time, so without this every CU of the chip loads its input (and later stores its output) at the same moment and
-    // computes at the same moment - HBM alternates between saturated and idle.  Speed only.
-    if (blockIdx.y == 0 && blockIdx.x < 256) {
-        const int n = (int)((blockIdx.x >> 3) & 15) * FB_STAGGER;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-    }
+#ifdef FB_STAMP
+    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
 #endif
-    fb_dma<RECP>(a.rec, slots + RECF, wave, lane);                  // record 0 (prologue GEMM) -> slot 1
-    fb_dma<RECP>(a.rec + RECF, slots, wave, lane);                  // record 1 (iteration 0)   -> slot 0
-    if constexpr (GATE) fb_dma<W2P>(a.w2, w2a, wave, lane);
+    int round = 0;
+    int item = item_of(0);
+    if (item >= a.items) return;
+    float xr[3][KS][8];
 
-    // ---------------------------------------------------------------- resident input: LayerNorm + fp16 split
-    fb_h8 xh[3][KS], xl[3][KS];
-    bool inside[3];
-    unsigned vq[3];                                // byte offset of (pixel, channel quad g) in LDS image 0
-    {
-        const float invC = 1.0f / (float)a.C;
-        const bool wb = a.ln_mode == IRM_LN_WITHBIAS;
+    for (;;) {
+        // Everything derived from the lane id is recomputed per item from an opaque copy: hoisted out of this loop,
+        // the lane-constant addresses and masks (dozens of registers) stay live across the whole item and spill.
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, g = lane >> 4, r = lane & 15;
+        // lane geometry inside a tile (item independent)
+        int hr[3], hc[3];
+        bool pv[3];
+        unsigned vq[3];                                // byte offset of (pixel, channel quad g) in LDS image 0
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int t = wave + 8 * j, p = 16 * t + r;
-            const bool pv = p < FB_NP;
-            const int hr = p / FB_HC, hc = p - hr * FB_HC;
-            const int gy = ty0 - 1 + hr, gx = tx0 - 1 + hc;
-            inside[j] = pv && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            vq[j] = fb_opaque((unsigned)(PL_OFF + ((pv ? p : FB_NP + r) * FB_PS + 4 * g) * 4));
-            const float* xp = X + (long)min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1);
-            float v[KS][8];
-            bool kin[KS][8];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = 32 * ks + 8 * g + e;
-                    kin[ks][e] = k < a.C;
-                    v[ks][e] = (FB_ABL & 128) ? (float)(k * 7 + r) * 0.01f : xp[(long)min(k, a.C - 1) * plane];
-                }
-            float s = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s += kin[ks][e] ? v[ks][e] : 0.f;
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            const float mean = s * invC;
-            float q = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float d = v[ks][e] - mean;
-                    q += kin[ks][e] ? d * d : 0.f;
-                    v[ks][e] = kin[ks][e] ? (wb ? d : v[ks][e]) : 0.f;
-                }
-            q += __shfl_xor(q, 16);
-            q += __shfl_xor(q, 32);
-            const float rs = 16.0f / sqrtf(q * invC + a.eps);          // operands carry a factor 2^4
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    // the product must be ONE rounded fp32 value for both parts: left to the compiler, hi comes from
-                    // cvt(fp32 product) and lo from a fused v_fma_mix against cvt(exact product) - they differ by
-                    // an fp16 ulp on double-rounding ties (1e-3 outliers)
-                    float xn = __fmul_rn(v[ks][e], rs);
-                    asm volatile("" : "+v"(xn));
-                    const _Float16 h = (_Float16)xn;
-                    xh[j][ks][e] = h;
-                    xl[j][ks][e] = (_Float16)(xn - (float)h);
-                }
+            const int p = 16 * (wave + 8 * j) + r;
+            pv[j] = p < FB_NP;
+            hr[j] = p / FB_HC;
+            hc[j] = p - hr[j] * FB_HC;
+            vq[j] = fb_opaque((unsigned)(PL_OFF + ((pv[j] ? p : FB_NP + r) * FB_PS + 4 * g) * 4));
         }
-    }
-    const unsigned vw = fb_opaque((unsigned)(lane * 16));             // MFMA weight operands: lane-linear 16-byte pieces
-    const unsigned vc = fb_opaque((unsigned)(16 * g));                // taps / bias of the lane's channel quad
-    const int sp0 = (2 * (wave >> 1)) * FB_HC + 16 * (wave & 1) + r;  // top-left tap in halo coordinates
-    const unsigned vp0 = fb_opaque((unsigned)(PL_OFF + (sp0 * FB_PS + 4 * g) * 4));
-    const unsigned vp1 = fb_opaque(vp0 + PL_B);
+        int klim[KS];                                  // channel 32 ks + 8 g + e exists <=> e < klim[ks] (compared where used:
+#pragma unroll                                     // 24 lane masks held in scalar registers spill)
+        for (int ks = 0; ks < KS; ++ks) klim[ks] = a.C - 32 * ks - 8 * g;
+        const unsigned vw = fb_opaque((unsigned)(lane * 16));             // MFMA weight operands: lane-linear 16-byte pieces
+        const unsigned vc = fb_opaque((unsigned)(16 * g));                // taps / bias of the lane's channel quad
+        const int sp0 = (2 * (wave >> 1)) * FB_HC + 16 * (wave & 1) + r;  // top-left tap in halo coordinates
+        const unsigned vp0 = fb_opaque((unsigned)(PL_OFF + (sp0 * FB_PS + 4 * g) * 4));
+        const unsigned vp1 = fb_opaque(vp0 + PL_B);
 
-    // One unit of the project_in GEMM of a stage = (16-channel tile hct, k-step ks): the weights are the A operand,
-    // so lane (r, g) receives hidden channels 4 g .. 4 g + 3 of pixel r; after the last k-step the tile goes to
-    // the LDS image img (+ bias, zero outside the image).  slot / img are compile-time constants at every call.
-    f32x4 acc1[3];
-    auto g1_load = [&](int hct, int ks, int slot, fb_h8& ah, fb_h8& al) {
-        ah = fb_ld<fb_h8>(lds, vw, slot * SLOT_B + ((hct * KS + ks) * 2) * 1024);
-        al = fb_ld<fb_h8>(lds, vw, slot * SLOT_B + ((hct * KS + ks) * 2 + 1) * 1024);
-    };
-    auto g1_comp = [&](int hct, int ks, int img, const fb_h8& ah, const fb_h8& al, const f32x4& b1) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (ks == 0) acc1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (FB_ABL & 2) { acc1[j][0] += (float)al[0] + (float)ah[1]; continue; }
-            acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[j][ks], acc1[j], 0, 0, 0);
-            acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[j][ks], acc1[j], 0, 0, 0);
-            acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[j][ks], acc1[j], 0, 0, 0);
-        }
-        if (ks == KS - 1) {
+        // raw input of an item: lane (r, g) -> halo pixel r of its 3 MFMA tiles, channels 32 ks + 8 g + e.  Addresses are
+        // (wave-uniform 64-bit base of channel 32 ks + e) + (32-bit lane offset): 12 offset registers instead of 72 pointers.
+        // Pixels outside the image read a clamped address (zeroed after the GEMM), channel groups beyond C a clamped
+        // group (masked by kin).
+        auto load_x = [&](int item) {
+            // its own opaque lane id: this runs in the last iteration, and none of its lane geometry may be live (in
+            // registers) across the iterations before it
+            int t2 = threadIdx.x;
+            asm volatile("" : "+v"(t2));
+            const int r2 = t2 & 15, g2 = (t2 & 63) >> 4;
+            const int b = item / a.tiles, tile = item - b * a.tiles;
+            const int ty0 = (tile / a.tiles_x) * FB_TH, tx0 = (tile % a.tiles_x) * FB_TW;
+            const float* X = a.X + (long)b * a.x_bs;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                f32x4 h;
+                const int p = 16 * (wave + 8 * j) + r2, ph = p / FB_HC, pc = p - ph * FB_HC;
+                const int gy = ty0 - 1 + ph, gx = tx0 - 1 + pc;
+                const unsigned pix = (unsigned)(min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = inside[j] ? fmaf(acc1[j][e], a.inv_s1, b1[e]) : 0.f;
-                fb_st<f32x4>(lds, vq[j], img * PL_B + hct * 64, h);
+                for (int ks = 0; ks < KS; ++ks) {
+                    const unsigned off = pix + (unsigned)(8 * min(g2, max((a.C - 32 * ks - 8) / 8, 0)) * plane);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xr[j][ks][e] = (X + (long)(32 * ks + e) * plane)[off];
+                }
+            }
+        };
+
+        if (round == 0) load_x(item);
+        const int b = item / a.tiles, tile = item - b * a.tiles;
+        const int ty0 = (tile / a.tiles_x) * FB_TH, tx0 = (tile % a.tiles_x) * FB_TW;
+        const float* X = a.X + (long)b * a.x_bs;
+        float* Y = a.Y + (long)b * a.y_bs;
+        const int nitem = item_of(round + 1);
+
+        FB_T(0);
+        // the previous item's last barrier has passed: every LDS region is free
+        fb_dma<RECP>(a.rec, slots + RECF, wave, lane);                  // record 0 (prologue GEMM) -> slot 1
+        fb_dma<RECP>(a.rec + RECF, slots, wave, lane);                  // record 1 (iteration 0)   -> slot 0
+        if constexpr (GATE) fb_dma<W2P>(a.w2, w2a, wave, lane);
+
+        // ------------------------------------------------------------ resident input: LayerNorm + fp16 split
+        fb_h8 xh[3][KS], xl[3][KS];
+        bool inside[3];
+        {
+            const float invC = 1.0f / (float)a.C;
+            const bool wb = a.ln_mode == IRM_LN_WITHBIAS;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int gy = ty0 - 1 + hr[j], gx = tx0 - 1 + hc[j];
+                inside[j] = pv[j] && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                float v[KS][8];
+                float s = 0.f;
+                int kl[KS];                            // opaque here: otherwise the 24 lane masks are hoisted out of the
+#pragma unroll                                         // item loop into scalar registers, which then spill
+                for (int ks = 0; ks < KS; ++ks) { kl[ks] = klim[ks]; asm volatile("" : "+v"(kl[ks])); }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { v[ks][e] = xr[j][ks][e]; s += e < kl[ks] ? v[ks][e] : 0.f; }
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                const float mean = s * invC;
+                float q = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float d = v[ks][e] - mean;
+                        q += e < kl[ks] ? d * d : 0.f;
+                        v[ks][e] = e < kl[ks] ? (wb ? d : v[ks][e]) : 0.f;
+                    }
+                q += __shfl_xor(q, 16);
+                q += __shfl_xor(q, 32);
+                const float rs = 16.0f / sqrtf(q * invC + a.eps);          // operands carry a factor 2^4
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        // the product must be ONE rounded fp32 value for both parts: left to the compiler, hi comes
+                        // from cvt(fp32 product) and lo from a fused v_fma_mix against cvt(exact product) - they
+                        // differ by an fp16 ulp on double-rounding ties (1e-3 outliers)
+                        float xn = __fmul_rn(v[ks][e], rs);
+                        asm volatile("" : "+v"(xn));
+                        const _Float16 h = (_Float16)xn;
+                        xh[j][ks][e] = h;
+                        xl[j][ks][e] = (_Float16)(xn - (float)h);
+                    }
             }
         }
-    };
-    auto gemm1_unit = [&](int hct, int ks, int slot, int img) {
-        fb_h8 ah, al;
-        g1_load(hct, ks, slot, ah, al);
-        const f32x4 b1 = fb_ld<f32x4>(lds, vc, slot * SLOT_B + CF_OFF + 320 * 4 + hct * 64);
-        g1_comp(hct, ks, img, ah, al, b1);
-    };
 
-    // One chunk of the depth-wise stencil = (channel half hf, halo row dy): lane (r, g) of wave w -> output rows
-    // 2 (w >> 1) + q, column 16 (w & 1) + r, channels 4 g + i of the half; row dy feeds tap row dy of q = 0 and tap
-    // row dy - 1 of q = 1 (packed-fp32 FMAs over channel pairs).  Loads and arithmetic are separate so that the
-    // loads of chunk i + 1 are in flight while chunk i computes.
-    float o[2][2][4];                              // [half][row q][channel]
-    f32x4 kprev[3];
-    auto st_comp = [&](int hf, int dy, const f32x4 (&P)[3], const f32x4 (&kc)[3], const f32x4& kb) {
-        // scalar v_fma_f32 on purpose (the file is built with -fno-slp-vectorize): packed fp32 FMAs do not
-        // co-execute with the MFMAs of the interleaved GEMM unit, plain ones do
-        if (dy == 0) {
+        FB_T(1);
+        __builtin_amdgcn_sched_barrier(0);
+        // project_out accumulators start from (residual + bias) in their own scale (s2 / 16, a power of two: exact)
+        f32x4 acc2[2][CT];
+        const int ox = tx0 + 16 * (wave & 1) + 4 * g, oy0 = ty0 + 2 * (wave >> 1);
+        if constexpr (GATE) {
+            const float rsc = 1.0f / a.inv_s2;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int co = 16 * c + r;
+                const bool cok = co < a.C && ox < a.W;
+                const float bv = (a.bias2 && co < a.C) ? a.bias2[co] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const bool ok = cok && oy0 + q < a.H;
+                    const float4 rr = *reinterpret_cast<const float4*>(X + (ok ? (long)co * plane + (long)(oy0 + q) * a.W + ox : 0));
+                    acc2[q][c] = (f32x4){(rr.x + bv) * rsc, (rr.y + bv) * rsc, (rr.z + bv) * rsc, (rr.w + bv) * rsc};
+                }
+            }
+        }
+
+        // One unit of the project_in GEMM of a stage = (16-channel tile hct, k-step ks): the weights are the A operand,
+        // so lane (r, g) receives hidden channels 4 g .. 4 g + 3 of pixel r; after the last k-step the tile goes to
+        // the LDS image img (+ bias, zero outside the image).  slot / img are compile-time constants at every call.
+        f32x4 acc1[3];
+        auto g1_comp = [&](int hct, int ks, int img, const fb_h8& ah, const fb_h8& al, const f32x4& b1) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (ks == 0) acc1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[j][ks], acc1[j], 0, 0, 0);
+                acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[j][ks], acc1[j], 0, 0, 0);
+                acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[j][ks], acc1[j], 0, 0, 0);
+            }
+            if (ks == KS - 1) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    f32x4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = inside[j] ? fmaf(acc1[j][e], a.inv_s1, b1[e]) : 0.f;
+                    fb_st<f32x4>(lds, vq[j], img * PL_B + hct * 64, h);
+                }
+            }
+        };
+        auto gemm1_unit = [&](int hct, int ks, int slot, int img) {
+            const fb_h8 ah = fb_ld<fb_h8>(lds, vw, slot * SLOT_B + ((hct * KS + ks) * 2) * 1024);
+            const fb_h8 al = fb_ld<fb_h8>(lds, vw, slot * SLOT_B + ((hct * KS + ks) * 2 + 1) * 1024);
+            const f32x4 b1 = fb_ld<f32x4>(lds, vc, slot * SLOT_B + CF_OFF + 320 * 4 + hct * 64);
+            g1_comp(hct, ks, img, ah, al, b1);
+        };
+
+        // One chunk of the depth-wise stencil = (channel half hf, halo row dy): lane (r, g) of wave w -> output rows
+        // 2 (w >> 1) + q, column 16 (w & 1) + r, channels 4 g + i of the half; row dy feeds tap row dy of q = 0 and
+        // tap row dy - 1 of q = 1.
+        float o[2][2][4];                              // [half][row q][channel]
+        f32x4 kprev[3];
+        auto st_comp = [&](int hf, int dy, const f32x4 (&P)[3], const f32x4 (&kc)[3], const f32x4& kb) {
+            // scalar v_fma_f32 (the file is built with -fno-slp-vectorize): as many issue slots as packed FMAs, and
+            // they pair with the MFMAs of the interleaved GEMM unit
+            if (dy == 0) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[hf][q][e] = kb[e];
+            }
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (dy < 3) o[hf][0][e] = fmaf(kc[dx][e], P[dx][e], o[hf][0][e]);
+                    if (dy > 0) o[hf][1][e] = fmaf(kprev[dx][e], P[dx][e], o[hf][1][e]);
+                }
+            }
+            if (dy < 3) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) kprev[dx] = kc[dx];
+            }
+            // pin the partial sums here: otherwise the compiler sinks the whole FMA chain to its consumer (the next
+            // iteration's project_out) and keeps every LDS read of the stage alive until then
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[hf][q][e] = kb[e];
-        }
+                for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(o[hf][q][e]));
+        };
+
+        FB_T(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        FB_T(3);
 #pragma unroll
-        for (int dx = 0; dx < ((FB_ABL & 1) ? 0 : 3); ++dx) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (dy < 3) o[hf][0][e] = fmaf(kc[dx][e], P[dx][e], o[hf][0][e]);
-                if (dy > 0) o[hf][1][e] = fmaf(kprev[dx][e], P[dx][e], o[hf][1][e]);
-            }
-        }
-        if (dy < 3) {
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) kprev[dx] = kc[dx];
-        }
-        // pin the partial sums here: otherwise the compiler sinks the whole FMA chain to its consumer (the next
-        // iteration's project_out) and keeps every LDS read of the stage alive until then
+        for (int u = 0; u < 2 * KS; ++u) gemm1_unit(u / KS, u % KS, 1, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        FB_T(4);
+
+        fb_h8 Gh[2], Gl[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(o[hf][q][e]));
-    };
+            for (int e = 0; e < 8; ++e) { Gh[q][e] = (_Float16)0.f; Gl[q][e] = (_Float16)0.f; }
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int u = 0; u < 2 * KS; ++u) gemm1_unit(u / KS, u % KS, 1, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    f32x4 acc2[2][CT];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc2[q][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    fb_h8 Gh[2], Gl[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { Gh[q][e] = (_Float16)0.f; Gl[q][e] = (_Float16)0.f; }
-
-    // iteration it: stencil of stage it (LDS image it & 1) interleaved with the GEMM of stage it + 1 (into the other
-    // image), chunk by chunk; project_out every second stage
-    float* Y = a.Y + (long)b * a.y_bs;
-    float oprev[2][2][4];
-    const int sy = ty0 + 2 * (wave >> 1), sx = tx0 + 16 * (wave & 1) + r;
-    const unsigned svoff = (unsigned)((4 * g) * plane + (long)sy * a.W + sx);
-    auto store_stage = [&](int st) {               // !GATE: stage st of the depth-wise outputs (oprev) -> Y
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float* yu = Y + (long)(32 * st + 16 * hf + e) * plane;          // wave-uniform part
-                const bool cok = 32 * st + 16 * hf + 4 * g + e < a.M && sx < a.W;
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    if (cok && sy + q < a.H) yu[svoff + q * a.W] = oprev[hf][q][e];
-            }
-    };
-    auto iter = [&](auto PAR, auto MORE, int it) {
-        constexpr int par = decltype(PAR)::value;
-        constexpr bool more = decltype(MORE)::value;
-        if constexpr (!GATE) { if (it > 0) store_stage(it - 1); }
-        if (more && !(FB_ABL & 64)) fb_dma<RECP>(a.rec + (long)(it + 2) * RECF, slots + (par ^ 1) * RECF, wave, lane);
-        if (GATE && par == 0 && it > 0 && !(FB_ABL & 64)) fb_dma<W2P>(a.w2 + (long)(it >> 1) * W2F, w2a, wave, lane);
-        {
-            const unsigned vp = par ? vp1 : vp0;
-            f32x4 P[2][3], K[2][3], KB[2], B1[2];
-            fb_h8 AH[2], AL[2];
-            // chunk I: stencil (half I >> 2, halo row I & 3) + GEMM unit (tile I / KS, k-step I % KS)
-            auto loads = [&](auto IC, auto NC) {
-                constexpr int I = decltype(IC)::value, n = decltype(NC)::value;
-                constexpr int hf = I >> 2, dy = I & 3;
-                constexpr int cf = par * SLOT_B + CF_OFF + hf * 64;
-                if constexpr ((FB_ABL & 16) != 0) {
-                    KB[n] = K[n][0] = K[n][1] = K[n][2] = P[n][0] = P[n][1] = P[n][2] = (f32x4){1.f, 2.f, 3.f, 4.f};
-                } else {
-                if constexpr (dy == 0) fb_dsr<cf + 9 * 128>(KB[n], vc);
-                if constexpr (dy < 3) {
-                    fb_dsr<cf + (dy * 3 + 0) * 128>(K[n][0], vc);
-                    fb_dsr<cf + (dy * 3 + 1) * 128>(K[n][1], vc);
-                    fb_dsr<cf + (dy * 3 + 2) * 128>(K[n][2], vc);
-                }
-                fb_dsr<(dy * FB_HC + 0) * (FB_PS * 4) + hf * 64>(P[n][0], vp);
-                fb_dsr<(dy * FB_HC + 1) * (FB_PS * 4) + hf * 64>(P[n][1], vp);
-                fb_dsr<(dy * FB_HC + 2) * (FB_PS * 4) + hf * 64>(P[n][2], vp);
-                }
-                if constexpr (more && I < 2 * KS) {
-                    constexpr int hct = I / KS, ks = I % KS;
-                    fb_dsr<par * SLOT_B + ((hct * KS + ks) * 2) * 1024>(AH[n], vw);
-                    fb_dsr<par * SLOT_B + ((hct * KS + ks) * 2 + 1) * 1024>(AL[n], vw);
-                    if constexpr (ks == KS - 1) fb_dsr<par * SLOT_B + CF_OFF + 320 * 4 + hct * 64>(B1[n], vc);
-                }
-            };
-            loads(fb_ic<0>{}, fb_ic<0>{});
-            fb_for<8>([&](auto IC) {
-                constexpr int I = decltype(IC)::value, c = I & 1, n = c ^ 1;
-                constexpr int hf = I >> 2, dy = I & 3;
-                if constexpr (I + 1 < 8) loads(fb_ic<I + 1>{}, fb_ic<n>{});
-                // LDS operations issued after the loads of chunk I: the loads of chunk I + 1
-                constexpr int J = I + 1, jdy = J & 3;
-                constexpr int nnext = J < 8 ? ((FB_ABL & 16) ? 0 : 3 + (jdy < 3 ? 3 : 0) + (jdy == 0 ? 1 : 0)) +
-                                                  ((more && J < 2 * KS) ? 2 + (J % KS == KS - 1 ? 1 : 0) : 0) : 0;
-                fb_waitcnt<nnext>();
-                fb_tie(P[c][0], P[c][1], P[c][2]);
-                if constexpr (dy < 3) fb_tie(K[c][0], K[c][1], K[c][2]);
-                if constexpr (dy == 0) fb_tie(KB[c]);
-                st_comp(hf, dy, P[c], K[c], KB[c]);
-                if constexpr (more && I < 2 * KS) {
-                    constexpr int hct = I / KS, ks = I % KS;
-                    fb_tie(AH[c], AL[c]);
-                    if constexpr (ks == KS - 1) fb_tie(B1[c]);
-                    g1_comp(hct, ks, par ^ 1, AH[c], AL[c], B1[c]);
-#if FB_INTERLEAVE
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) {
-                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x2, FB_INTERLEAVE, 0);
-                    }
-#endif
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        }
-        if constexpr (!GATE) {
+        float oprev[2][2][4];
+        const int sy = ty0 + 2 * (wave >> 1), sx = tx0 + 16 * (wave & 1) + r;
+        const unsigned svoff = (unsigned)((4 * g) * plane + (long)sy * a.W + sx);
+        auto store_stage = [&](int st) {               // !GATE: stage st of the depth-wise outputs (oprev) -> Y
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float* yu = Y + (long)(32 * st + 16 * hf + e) * plane;          // wave-uniform part
+                    const bool cok = 32 * st + 16 * hf + 4 * g + e < a.M && sx < a.W;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (cok && sy + q < a.H) yu[svoff + q * a.W] = oprev[hf][q][e];
+                }
+        };
+
+        // iteration it: stencil of stage it (LDS image it & 1) interleaved with the GEMM of stage it + 1 (into the other
+        // image), chunk by chunk; project_out every second stage.  The last iteration (more = false) has no GEMM: its
+        // operand registers take the raw input of the next item.
+        auto iter = [&](auto PAR, auto MORE, int it) {
+            constexpr int par = decltype(PAR)::value;
+            constexpr bool more = decltype(MORE)::value;
+            if constexpr (!GATE) { if (it > 0) store_stage(it - 1); }
+            if constexpr (more) fb_dma<RECP>(a.rec + (long)(it + 2) * RECF, slots + (par ^ 1) * RECF, wave, lane);
+            if (GATE && par == 0 && it > 0) fb_dma<W2P>(a.w2 + (long)(it >> 1) * W2F, w2a, wave, lane);
+            if constexpr (!more) {
+                // unconditional (the last round re-reads a valid item for nothing): under "if (there is a next item)"
+                // the old values would have to stay alive through every iteration of this item, 72 registers
+                load_x(min(nitem, a.items - 1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {
+                const unsigned vp = par ? vp1 : vp0;
+                f32x4 P[2][3], K[2][3], KB[2], B1[2];
+                fb_h8 AH[2], AL[2];
+                // chunk I: stencil (half I >> 2, halo row I & 3) + GEMM unit (tile I / KS, k-step I % KS)
+                auto loads = [&](auto IC, auto NC) {
+                    constexpr int I = decltype(IC)::value, n = decltype(NC)::value;
+                    constexpr int hf = I >> 2, dy = I & 3;
+                    constexpr int cf = par * SLOT_B + CF_OFF + hf * 64;
+                    if constexpr (dy == 0) fb_dsr<cf + 9 * 128>(KB[n], vc);
+                    if constexpr (dy < 3) {
+                        fb_dsr<cf + (dy * 3 + 0) * 128>(K[n][0], vc);
+                        fb_dsr<cf + (dy * 3 + 1) * 128>(K[n][1], vc);
+                        fb_dsr<cf + (dy * 3 + 2) * 128>(K[n][2], vc);
+                    }
+                    fb_dsr<(dy * FB_HC + 0) * (FB_PS * 4) + hf * 64>(P[n][0], vp);
+                    fb_dsr<(dy * FB_HC + 1) * (FB_PS * 4) + hf * 64>(P[n][1], vp);
+                    fb_dsr<(dy * FB_HC + 2) * (FB_PS * 4) + hf * 64>(P[n][2], vp);
+                    if constexpr (more && I < 2 * KS) {
+                        constexpr int hct = I / KS, ks = I % KS;
+                        fb_dsr<par * SLOT_B + ((hct * KS + ks) * 2) * 1024>(AH[n], vw);
+                        fb_dsr<par * SLOT_B + ((hct * KS + ks) * 2 + 1) * 1024>(AL[n], vw);
+                        if constexpr (ks == KS - 1) fb_dsr<par * SLOT_B + CF_OFF + 320 * 4 + hct * 64>(B1[n], vc);
+                    }
+                };
+                // (the last iteration carries the next item's raw input in registers instead of the second operand
+                // buffer: its chunks load and wait in place)
+                if constexpr (more) loads(fb_ic<0>{}, fb_ic<0>{});
+                fb_for<8>([&](auto IC) {
+                    constexpr int I = decltype(IC)::value, c = more ? (I & 1) : 0, n = c ^ 1;
+                    constexpr int hf = I >> 2, dy = I & 3;
+                    if constexpr (more && I + 1 < 8) loads(fb_ic<I + 1>{}, fb_ic<n>{});
+                    if constexpr (!more) loads(fb_ic<I>{}, fb_ic<0>{});
+                    // LDS operations issued after the loads of chunk I: the loads of chunk I + 1
+                    constexpr int J = I + 1, jdy = J & 3;
+                    constexpr int nnext = (more && J < 8) ? 3 + (jdy < 3 ? 3 : 0) + (jdy == 0 ? 1 : 0) +
+                                                      ((more && J < 2 * KS) ? 2 + (J % KS == KS - 1 ? 1 : 0) : 0) : 0;
+                    fb_waitcnt<nnext>();
+                    fb_tie(P[c][0], P[c][1], P[c][2]);
+                    if constexpr (dy < 3) fb_tie(K[c][0], K[c][1], K[c][2]);
+                    if constexpr (dy == 0) fb_tie(KB[c]);
+                    st_comp(hf, dy, P[c], K[c], KB[c]);
+                    if constexpr (more && I < 2 * KS) {
+                        constexpr int hct = I / KS, ks = I % KS;
+                        fb_tie(AH[c], AL[c]);
+                        if constexpr (ks == KS - 1) fb_tie(B1[c]);
+                        g1_comp(hct, ks, par ^ 1, AH[c], AL[c], B1[c]);
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) {
+                            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, FB_INTERLEAVE, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            if constexpr (!GATE) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) oprev[hf][q][e] = o[hf][q][e];
+            }
+#pragma unroll
+            for (int q = 0; q < (GATE ? 2 : 0); ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float gx = __fmul_rn(fb_gelu1(o[0][q][e]) * o[1][q][e], 0.0625f);
+                    asm volatile("" : "+v"(gx));         // one rounded value for hi and lo (see the input split)
+                    const _Float16 h = (_Float16)gx;
+                    Gh[q][4 * par + e] = h;
+                    Gl[q][4 * par + e] = (_Float16)(gx - (float)h);
+                }
+#pragma unroll
+            for (int q = 0; q < (GATE ? 2 : 0); ++q) asm volatile("" : "+v"(Gh[q]), "+v"(Gl[q]));
+            if (GATE && (par == 1 || !more)) {
+                if constexpr (par == 0) {
+                    // odd stage count: this super-stage's project_out weights were requested in this very iteration
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const fb_h8 bh = fb_ld<fb_h8>(lds, vw, W2_OFF + (c * 2) * 1024);
+                    const fb_h8 bl = fb_ld<fb_h8>(lds, vw, W2_OFF + (c * 2 + 1) * 1024);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        acc2[q][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Gl[q], bh, acc2[q][c], 0, 0, 0);
+                        acc2[q][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Gh[q], bl, acc2[q][c], 0, 0, 0);
+                        acc2[q][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Gh[q], bh, acc2[q][c], 0, 0, 0);
+                    }
+                }
+#pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) oprev[hf][q][e] = o[hf][q][e];
-        }
-#pragma unroll
-        for (int q = 0; q < (GATE ? 2 : 0); ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float gx = __fmul_rn(((FB_ABL & 4) ? o[0][q][e] : fb_gelu1(o[0][q][e])) * o[1][q][e], 0.0625f);
-                asm volatile("" : "+v"(gx));         // one rounded value for hi and lo (see the input split)
-                const _Float16 h = (_Float16)gx;
-                Gh[q][4 * par + e] = h;
-                Gl[q][4 * par + e] = (_Float16)(gx - (float)h);
+                    for (int e = 0; e < 8; ++e) { Gh[q][e] = (_Float16)0.f; Gl[q][e] = (_Float16)0.f; }
             }
-#pragma unroll
-        for (int q = 0; q < (GATE ? 2 : 0); ++q) asm volatile("" : "+v"(Gh[q]), "+v"(Gl[q]));
-        if (GATE && (par == 1 || !more) && !(FB_ABL & 8)) {
+            // the weight DMAs of this iteration must have landed; the last iteration issued none (only the next
+            // item's input, which must NOT be waited for here)
+            if constexpr (more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+        {
+            const std::integral_constant<int, 0> P0; const std::integral_constant<int, 1> P1;
+            const std::true_type T; const std::false_type F;
+            int it = 0;
+            for (; it + 2 < S; it += 2) { iter(P0, T, it); iter(P1, T, it + 1); }
+            if (it + 2 == S) { iter(P0, T, it); FB_T(5); iter(P1, F, it + 1); }
+            else { FB_T(5); iter(P0, F, it); }
+            FB_T(6);
+        }
+
+        if constexpr (!GATE) {
+            store_stage(S - 1);
+        } else {
+            // -------------------------------------------------------- epilogue: 16-byte stores
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                const fb_h8 bh = fb_ld<fb_h8>(lds, vw, W2_OFF + (c * 2) * 1024);
-                const fb_h8 bl = fb_ld<fb_h8>(lds, vw, W2_OFF + (c * 2 + 1) * 1024);
+                const int co = 16 * c + r;
+                if (co >= a.C || ox >= a.W) continue;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    acc2[q][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Gl[q], bh, acc2[q][c], 0, 0, 0);
-                    acc2[q][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Gh[q], bl, acc2[q][c], 0, 0, 0);
-                    acc2[q][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Gh[q], bh, acc2[q][c], 0, 0, 0);
+                    if (oy0 + q >= a.H) continue;
+                    const float4 v = make_float4(acc2[q][c][0] * a.inv_s2, acc2[q][c][1] * a.inv_s2,
+                                                 acc2[q][c][2] * a.inv_s2, acc2[q][c][3] * a.inv_s2);
+                    *reinterpret_cast<float4*>(Y + (long)co * plane + (long)(oy0 + q) * a.W + ox) = v;
                 }
             }
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { Gh[q][e] = (_Float16)0.f; Gl[q][e] = (_Float16)0.f; }
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-    {
-        const std::integral_constant<int, 0> P0; const std::integral_constant<int, 1> P1;
-        const std::true_type T; const std::false_type F;
-        int it = 0;
-        for (; it + 2 < S; it += 2) { iter(P0, T, it); iter(P1, T, it + 1); }
-        if (it + 2 == S) { iter(P0, T, it); iter(P1, F, it + 1); }
-        else iter(P0, F, it);
+        FB_T(7);
+        if (nitem >= a.items) break;
+        item = nitem;
+        ++round;
     }
-
-    if constexpr (!GATE) { store_stage(S - 1); return; }
-    // ---------------------------------------------------------------- epilogue: + bias + residual, 16-byte stores
-    const int ox = tx0 + 16 * (wave & 1) + 4 * g;
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        const int co = 16 * c + r;
-        if (co >= a.C) continue;
-        const float bv = a.bias2 ? a.bias2[co] : 0.0f;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int oy = ty0 + 2 * (wave >> 1) + q;
-            if (oy >= a.H || ox >= a.W) continue;
-            const long off = (long)co * plane + (long)oy * a.W + ox;
-            const float4 rr = (FB_ABL & 256) ? make_float4(1.f, 2.f, 3.f, 4.f) : *reinterpret_cast<const float4*>(X + off);
-            float4 v;
-            v.x = fmaf(acc2[q][c][0], a.inv_s2, rr.x + bv);
-            v.y = fmaf(acc2[q][c][1], a.inv_s2, rr.y + bv);
-            v.z = fmaf(acc2[q][c][2], a.inv_s2, rr.z + bv);
-            v.w = fmaf(acc2[q][c][3], a.inv_s2, rr.w + bv);
-            if (!(FB_ABL & 512) || v.x == 12345.678f) *reinterpret_cast<float4*>(Y + off) = v;
-        }
-    }
+#ifdef FB_STAMP
+    if (threadIdx.x == 0 && a.dbg)
+        for (int i = 0; i < 8; ++i) a.dbg[blockIdx.x * 8 + i] = stamp[i];
+#endif
 }
 
 template <int KS, int CT, bool GATE = true>
@@ -494,8 +579,18 @@ static int gdfn_launch(FusedArgs a, int B, hipStream_t stream) {
     }
     a.tiles_x = (a.W + FB_TW - 1) / FB_TW;
     a.tiles = a.tiles_x * ((a.H + FB_TH - 1) / FB_TH);
-    const int per = (a.tiles + 7) >> 3;
-    hipLaunchKernelGGL((lnpw_dw_fused_kernel<KS, CT, GATE>), dim3(per * 8, B), dim3(512), lds, stream, a);
+    a.items = B * a.tiles;
+    static int cus_dev[64] = {0};
+    if (!cus_dev[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return IRM_ELAUNCH;
+        cus_dev[dev] = n;
+    }
+    // one workgroup per CU (the kernel holds ~150 KiB of LDS), in whole groups of 8 (one per XCD)
+    const int per = (a.items + 7) >> 3;
+    a.gpx = (cus_dev[dev] + 7) / 8;
+    if (a.gpx > per) a.gpx = per;
+    hipLaunchKernelGGL((lnpw_dw_fused_kernel<KS, CT, GATE>), dim3(a.gpx * 8), dim3(512), lds, stream, a);
     return irm_launch_status();
 }
 
@@ -503,13 +598,16 @@ extern "C" int irm_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const
                                         float* y, long y_bs, int ln_mode, float eps, float inv_s1, float inv_s2, int B,
                                         int C, int hid, int H, int W, hipStream_t stream) {
     if (!rec || !w2 || !x || !y || x == y || B <= 0 || C <= 0 || hid <= 0 || H <= 0 || W <= 0) return IRM_EINVAL;
-    if (C > 96 || (W & 3) || B > 65535) return IRM_EINVAL;
+    if (C > 96 || (W & 3)) return IRM_EINVAL;
     if (ln_mode != IRM_LN_WITHBIAS && ln_mode != IRM_LN_BIASFREE) return IRM_EINVAL;
     if ((x_bs & 3) || (y_bs & 3) || !irm_aligned16(x) || !irm_aligned16(y) || !irm_aligned16(rec) || !irm_aligned16(w2))
         return IRM_EINVAL;
     FusedArgs a;
     a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.rec = rec; a.w2 = w2; a.bias2 = bias2;
     a.C = C; a.H = H; a.W = W; a.S = (hid + 15) / 16; a.M = 0; a.ln_mode = ln_mode; a.eps = eps; a.inv_s1 = inv_s1; a.inv_s2 = inv_s2;
+#ifdef FB_STAMP
+    a.dbg = getenv("FB_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FB_DBG_PTR"), nullptr, 0) : nullptr;
+#endif
     a.tiles_x = 0; a.tiles = 0;
     const int ks = (C + 31) / 32, ct = (C + 15) / 16;
     if (ks == 3) {
@@ -526,12 +624,15 @@ extern "C" int irm_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const
 extern "C" int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode,
                                           float eps, float inv_s1, int B, int C, int M, int H, int W, hipStream_t stream) {
     if (!rec || !x || !y || x == y || B <= 0 || C <= 0 || M <= 0 || H <= 0 || W <= 0) return IRM_EINVAL;
-    if (C > 96 || (W & 3) || B > 65535 || (long)M * H * W >= (1L << 30)) return IRM_EINVAL;
+    if (C > 96 || (W & 3) || (long)M * H * W >= (1L << 30)) return IRM_EINVAL;
     if (ln_mode != IRM_LN_WITHBIAS && ln_mode != IRM_LN_BIASFREE) return IRM_EINVAL;
     if ((x_bs & 3) || (y_bs & 3) || !irm_aligned16(x) || !irm_aligned16(y) || !irm_aligned16(rec)) return IRM_EINVAL;
     FusedArgs a;
     a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.rec = rec; a.w2 = nullptr; a.bias2 = nullptr;
     a.C = C; a.H = H; a.W = W; a.S = (M + 31) / 32; a.M = M; a.ln_mode = ln_mode; a.eps = eps; a.inv_s1 = inv_s1; a.inv_s2 = 0.f;
+#ifdef FB_STAMP
+    a.dbg = getenv("FB_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FB_DBG_PTR"), nullptr, 0) : nullptr;
+#endif
     a.tiles_x = 0; a.tiles = 0;
     switch ((C + 31) / 32) {
         case 3: return gdfn_launch<3, 1, false>(a, B, stream);
