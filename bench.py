@@ -13,16 +13,25 @@ Frames are resident in HBM before the timed region; the uint8 result stays on
 the device.  Images are independent units: rank r processes its own frames, no
 data-path collective; PSNR rows are gathered once at the end (RCCL all_gather).
 
+`python bench.py --gpus N` without a launcher starts its own N ranks (a child
+`python -m torch.distributed.run`, before anything touches a GPU) and exits with
+their status.
+
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
-(the dominant kernel: the f32-MFMA 1x1 GEMM, timed with HIP events on the launch
-stream during the timed steps) and `cpu_baseline` (the CPU oracle on the host
-cores over a bounded sample, N=1 only).
+(the kernel group with the largest share of the kernel time, timed with HIP
+events on the launch stream during the timed steps), `cpu_baseline` (the CPU
+oracle on the host cores over a bounded sample, N=1 only) and, at N=1, two
+reference legs measured in child processes: `value_exact_f32` (every GEMM on the
+f32-input MFMA, IRM_GEMM_EXACT=1) and `value_pcie_inclusive` (the reference-shaped
+get_model_prediction call: numpy uint8 in host memory -> numpy uint8).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,7 +47,12 @@ from irm_amd import ops, parallel, restormer, synth, utils  # noqa: E402
 from irm_amd.configs import PATCH_CONFIG  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec peak
+# SURVEY 8(d) / BASELINE.md section 3: the reference's op-boundary decomposition of one 1280x720 frame (every
+# op's inputs read once, outputs written once, fp32) and its FLOPs - the fixed yardstick of the whole step,
+# independent of how many of those boundaries this build has fused away
+REF_STEP_GBYTES, REF_STEP_TFLOP = 271.1, 7.54
 H, W, C = 720, 1280, 3
 N_FRAMES = 4                      # distinct synthetic frames per rank, cycled over the steps
 
@@ -53,7 +67,53 @@ def parse():
     ap.add_argument("--streams", type=int, default=1, help="tile groups run on this many HIP streams")
     ap.add_argument("--detail", default=None, help="write a per-shape kernel table (json) to this path")
     ap.add_argument("--cpu-tile", type=int, default=512, help="tile edge of the CPU-baseline sample")
+    ap.add_argument("--no-legs", action="store_true", help="skip the exact-f32 / PCIe-inclusive child legs")
+    ap.add_argument("--leg", choices=["pcie"], default=None, help=argparse.SUPPRESS)     # child process mode
     return ap.parse_args()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: run the N ranks as a child torch.distributed.run
+    and return its exit code.  Nothing in this process has touched a GPU (no exec after GPU initialisation)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def child_leg(extra_args, env_extra, timeout=600):
+    """One measurement in a child process (fresh library state / environment); returns its JSON line or None."""
+    cmd = [sys.executable, os.path.abspath(__file__)] + extra_args
+    try:
+        r = subprocess.run(cmd, env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=timeout)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+    except (subprocess.SubprocessError, ValueError, OSError):
+        pass
+    return None
+
+
+def pcie_leg(dev, steps, warmup):
+    """The reference-shaped synchronous call (src/utils.py:353-454: numpy uint8 frame in host memory ->
+    get_model_prediction -> numpy uint8 frame; one H2D, one D2H and a host synchronisation per frame)."""
+    model = restormer.Restormer(LayerNorm_type="WithBias").load_synthetic(42).eval().to(dev)
+    cfg = utils.get_patch_config("deblurring", "motion", "Restormer")
+    frames = [synth.synth_image_pair(i, H, W, C, seed_base=1000, blur=15)[0] for i in range(N_FRAMES)]
+    for i in range(warmup):
+        utils.get_model_prediction(model, frames[i % N_FRAMES], dev, **cfg)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        utils.get_model_prediction(model, frames[i % N_FRAMES], dev, **cfg)
+    dt = (time.perf_counter() - t0) / steps
+    print(json.dumps({"value": 1.0 / dt, "ms_per_step": dt * 1e3, "steps": steps}))
 
 
 def cpu_baseline(model, frame_u8, gpu_tile, tile_edge):
@@ -63,7 +123,10 @@ def cpu_baseline(model, frame_u8, gpu_tile, tile_edge):
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     x = tiler_ref.to_unit_range(frame_u8)[:tile_edge, :tile_edge]
     t = torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))[None]
-    threads = torch.get_num_threads()
+    # the GPU box gives a 1-GPU job a share of the host (16 CPUs), not the 256 it reports: 128 torch threads
+    # oversubscribe that share and under-state the CPU
+    threads = max(1, min(int(os.environ.get("IRM_CPU_THREADS", "16")), os.cpu_count() or 1))
+    torch.set_num_threads(threads)
     t0 = time.time()
     with torch.no_grad():
         y = restormer_ref.restormer_forward(t, sd)
@@ -80,6 +143,11 @@ def cpu_baseline(model, frame_u8, gpu_tile, tile_edge):
 
 #: timer group -> (kernel label, roofline that bounds it, regex of its instantiations in the PMC table)
 ROOFLINE_KERNELS = {
+    "gdfn_fused": ("lnpw_dw_fused_kernel<GATE> (irm_gdfn_fused_f16x3_f32: LayerNorm + project_in + depth-wise 3x3 + GELU gate + "
+                   "project_out + residual in one kernel; 1x1 convs = fp32 emulated by three fp16 MFMAs)", "mfma",
+                   r"^lnpw_dw_fused_kernel<.*, true>"),
+    "qkv_dw_fused": ("lnpw_dw_fused_kernel<!GATE> (irm_qkv_dw_fused_f16x3_f32: LayerNorm + qkv 1x1 + depth-wise 3x3)", "hbm",
+                     r"^lnpw_dw_fused_kernel<.*, false>"),
     "gemm1x1_f16x3": ("gemm_xres_kernel / gemm_ring_kernel<F16> (irm_gemm1x1_f16x3_f32: LayerNorm + 1x1 conv, fp32 emulated "
                       "by three fp16 MFMAs, fp32 accumulate)", "hbm", r"^(gemm_ring_kernel<.*, true>|gemm_xres_kernel)"),
     "gemm1x1": ("gemm_ring_kernel (irm_gemm1x1_f32, exact f32 MFMA)", "mfma", r"^gemm_(ring_kernel<.*, false>|pw_kernel.*)$"),
@@ -96,15 +164,29 @@ def pmc_traffic(pattern):
     MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_traffic.py).  None when the file is absent: the
     counters cannot be read from inside an unprofiled run."""
     import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "g_final_pmc_traffic.json")
     try:
-        with open(path) as f:
+        with open(PMC_FILE) as f:
             d = json.load(f)
     except OSError:
         return None
-    rows = [v for k, v in d.items() if re.search(pattern, k) and v.get("hbm_bytes_per_launch") is not None]
+    rows = [v for k, v in d.items() if not k.startswith("_") and re.search(pattern, k)
+            and v.get("hbm_bytes_per_launch") is not None]
     n = sum(v["launches"] for v in rows)
     return sum(v["launches"] * v["hbm_bytes_per_launch"] for v in rows) / n if n else None
+
+
+PMC_FILE = os.path.join(ROOT, "profiles", "r02", "final_pmc_traffic.json")
+
+
+def pmc_provenance():
+    """Where the PMC traffic figure comes from: the committed file and the git revision it was collected at
+    (written into the file by tools/pmc_traffic.py as "_git_sha")."""
+    try:
+        with open(PMC_FILE) as f:
+            sha = json.load(f).get("_git_sha")
+    except OSError:
+        return None
+    return {"file": os.path.relpath(PMC_FILE, ROOT), "collected_at_git_sha": sha}
 
 
 def main():
@@ -114,10 +196,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))              # no GPU call has happened in this process
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.leg == "pcie":
+        return pcie_leg(dev, args.steps, args.warmup)
     dist = None
     if world > 1 or "RANK" in os.environ:         # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
@@ -184,7 +268,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if os.environ.get("IRM_GEMM_EXACT") else
                      "f32 (1x1 convs: fp32 emulated by 3 fp16 MFMAs on hi/lo operand splits with fp32 accumulation, "
-                     "error vs float64 <= the exact-f32 kernel's; everything else exact f32; IRM_GEMM_EXACT=1: "
+                     "error vs float64 at the level of an fp32 chain; everything else exact f32; value_exact_f32: "
                      "f32 MFMA everywhere)",
             "data": "synthetic",
             "config": {"workload": "Restormer motion-deblur (WithBias LN, 26.13M params, synthetic weights seed 42) on "
@@ -213,13 +297,23 @@ def main():
             dom = max(ks, key=lambda k: ks[k]["ms"])
             g = ks[dom]
             label, bound, pmc_re = ROOFLINE_KERNELS.get(dom, (dom, "hbm", None))
-            if bound == "mfma":
+            emulated = dom in ("gdfn_fused", "qkv_dw_fused", "gemm1x1_f16x3", "dwgemm_f16x3")
+            if bound == "mfma" and emulated:
+                # the unit that executes the arithmetic is the fp16 matrix core: three MFMA passes per fp32 product
+                ach, peak, unit = 3.0 * g["flops"] / (g["ms"] * 1e-3) / 1e12, PEAK_F16_MFMA_TFLOPS, "TFLOP/s"
+            elif bound == "mfma":
                 ach, peak, unit = g["flops"] / (g["ms"] * 1e-3) / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
             else:
                 ach, peak, unit = g["bytes"] / (g["ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
             out["roofline"] = {"kernel": label, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
                                "frac": ach / peak, "traffic": pmc_traffic(pmc_re) if pmc_re else None,
-                               "traffic_unit": "bytes per launch (HBM, PMC)",
+                               "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": pmc_provenance(),
+                               "note": ("achieved = 3 x algorithmic fp32 FLOPs (2 M K N per 1x1 conv + 18 per depth-wise output; "
+                                        "3 = the fp16 MFMA passes of the fp32 emulation; halo recompute not counted) / "
+                                        "HIP-event time, against the dense fp16 MFMA peak; fp32_equivalent_tflops is the "
+                                        "same without the factor 3 (f32-input MFMA peak: 157.3)") if bound == "mfma" and emulated else
+                                       "achieved = algorithmic fp32 FLOPs / HIP-event time vs the f32-input MFMA peak" if bound == "mfma" else
+                                       "achieved = algorithmic bytes (inputs once, outputs once, fp32) / HIP-event time",
                                "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
                                "fp32_equivalent_tflops": g["flops"] / (g["ms"] * 1e-3) / 1e12,
                                "launches": g["launches"],
@@ -233,9 +327,30 @@ def main():
             # whole-step bound: max(F/peakF, B/peakB) / t  
             F = sum(v["flops"] for v in ks.values()) / args.steps
             Bt = sum(v["bytes"] for v in ks.values()) / args.steps
-            bound_s = max(F / (PEAK_F32_MFMA_TFLOPS * 1e12), Bt / (PEAK_HBM_GBS * 1e9))
-            out["step_model"] = {"gflop": F / 1e9, "gbytes": Bt / 1e9, "bound_ms": bound_s * 1e3,
-                                 "frac_of_bound": bound_s / (elapsed / args.steps)}
+            exact = bool(os.environ.get("IRM_GEMM_EXACT"))
+            t_step = elapsed / args.steps
+            hbm_ms, mfma_ms = REF_STEP_GBYTES / PEAK_HBM_GBS * 1e3, REF_STEP_TFLOP / PEAK_F32_MFMA_TFLOPS * 1e3
+            # the bound that applies to the arithmetic actually run: with the 1x1 convs emulated on the fp16 cores the
+            # f32-MFMA bound no longer binds, the reference's kernel-boundary HBM traffic does
+            bound_ms = max(hbm_ms, mfma_ms) if exact else hbm_ms
+            out["step_model"] = {
+                "reference_gbytes": REF_STEP_GBYTES, "reference_tflop": REF_STEP_TFLOP,
+                "hbm_bound_ms": hbm_ms, "f32_mfma_bound_ms": mfma_ms, "bound": "f32 mfma" if exact and mfma_ms > hbm_ms else "hbm",
+                "bound_ms": bound_ms, "frac_of_bound": bound_ms / (t_step * 1e3),
+                "this_build_kernel_boundary_gbytes": Bt / 1e9, "this_build_algorithmic_gflop": F / 1e9,
+                "note": "reference_* = the reference's op-boundary decomposition (SURVEY 8d); this_build_* = what is left "
+                        "at this build's kernel boundaries after fusion (timer rows)"}
+        if world == 1 and not args.no_legs and not os.environ.get("IRM_GEMM_EXACT"):
+            # reference legs, each in its own process (the emulation switch is read when the weights are packed)
+            torch.cuda.synchronize()
+            ex = child_leg(["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-timer", "--no-legs"],
+                           {"IRM_GEMM_EXACT": "1"})
+            out["value_exact_f32"] = None if ex is None else ex["value"]
+            out["value_exact_f32_note"] = "IRM_GEMM_EXACT=1: every GEMM on the f32-input MFMA, no fused branch kernels; 5 steps"
+            pc = child_leg(["--leg", "pcie", "--steps", "8", "--warmup", "2"], {})
+            out["value_pcie_inclusive"] = None if pc is None else pc["value"]
+            out["value_pcie_inclusive_note"] = ("get_model_prediction(model, numpy_frame, device, **patch_config): uint8 frame in "
+                                                "host memory -> uint8 frame in host memory, synchronous, 8 frames")
         if world == 1 and not args.no_cpu_baseline:
             gpu_tile = keep[0][0] if keep else None
             out["cpu_baseline"] = cpu_baseline(model, host_frames[0][0], gpu_tile, args.cpu_tile)

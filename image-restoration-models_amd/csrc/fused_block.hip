@@ -295,8 +295,8 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         // project_out accumulators start from (residual + bias) in their own scale (s2 / 16, a power of two: exact)
         f32x4 acc2[2][CT];
-        const int ox = tx0 + 16 * (wave & 1) + 4 * g, oy0 = ty0 + 2 * (wave >> 1);
         if constexpr (GATE) {
+            const int ox = tx0 + 16 * (wave & 1) + 4 * g, oy0 = ty0 + 2 * (wave >> 1);
             const float rsc = 1.0f / a.inv_s2;
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
@@ -392,9 +392,11 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             for (int e = 0; e < 8; ++e) { Gh[q][e] = (_Float16)0.f; Gl[q][e] = (_Float16)0.f; }
 
         float oprev[2][2][4];
-        const int sy = ty0 + 2 * (wave >> 1), sx = tx0 + 16 * (wave & 1) + r;
-        const unsigned svoff = (unsigned)((4 * g) * plane + (long)sy * a.W + sx);
         auto store_stage = [&](int st) {               // !GATE: stage st of the depth-wise outputs (oprev) -> Y
+            int t4 = threadIdx.x;
+            asm volatile("" : "+v"(t4));
+            const int g = (t4 & 63) >> 4, sy = ty0 + 2 * (wave >> 1), sx = tx0 + 16 * (wave & 1) + (t4 & 15);
+            const unsigned svoff = (unsigned)((4 * g) * plane + (long)sy * a.W + sx);
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -416,22 +418,24 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             if constexpr (!GATE) { if (it > 0) store_stage(it - 1); }
             if constexpr (more) fb_dma<RECP>(a.rec + (long)(it + 2) * RECF, slots + (par ^ 1) * RECF, wave, lane);
             if (GATE && par == 0 && it > 0) fb_dma<W2P>(a.w2 + (long)(it >> 1) * W2F, w2a, wave, lane);
-            if constexpr (!more) {
+            if constexpr (!more && par == 1) {
                 // unconditional (the last round re-reads a valid item for nothing): under "if (there is a next item)"
-                // the old values would have to stay alive through every iteration of this item, 72 registers
+                // the old values would have to stay alive through every iteration of this item, 72 registers.
+                // (Odd stage counts end on the par == 0 instance, which also holds the first half of the project_out
+                // operands: there the request waits until the iteration is over.)
                 load_x(min(nitem, a.items - 1));
                 __builtin_amdgcn_sched_barrier(0);
             }
             {
                 const unsigned vp = par ? vp1 : vp0;
-                f32x4 P[2][3], K[2][3], KB[2], B1[2];
+                f32x4 P[2][3], K[2][3], KB[1], B1[KS == 1 ? 2 : 1];   // (tap / GEMM bias: not in consecutive chunks unless KS == 1)
                 fb_h8 AH[2], AL[2];
                 // chunk I: stencil (half I >> 2, halo row I & 3) + GEMM unit (tile I / KS, k-step I % KS)
                 auto loads = [&](auto IC, auto NC) {
                     constexpr int I = decltype(IC)::value, n = decltype(NC)::value;
                     constexpr int hf = I >> 2, dy = I & 3;
                     constexpr int cf = par * SLOT_B + CF_OFF + hf * 64;
-                    if constexpr (dy == 0) fb_dsr<cf + 9 * 128>(KB[n], vc);
+                    if constexpr (dy == 0) fb_dsr<cf + 9 * 128>(KB[0], vc);
                     if constexpr (dy < 3) {
                         fb_dsr<cf + (dy * 3 + 0) * 128>(K[n][0], vc);
                         fb_dsr<cf + (dy * 3 + 1) * 128>(K[n][1], vc);
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                         constexpr int hct = I / KS, ks = I % KS;
                         fb_dsr<par * SLOT_B + ((hct * KS + ks) * 2) * 1024>(AH[n], vw);
                         fb_dsr<par * SLOT_B + ((hct * KS + ks) * 2 + 1) * 1024>(AL[n], vw);
-                        if constexpr (ks == KS - 1) fb_dsr<par * SLOT_B + CF_OFF + 320 * 4 + hct * 64>(B1[n], vc);
+                        if constexpr (ks == KS - 1) fb_dsr<par * SLOT_B + CF_OFF + 320 * 4 + hct * 64>(B1[KS == 1 ? n : 0], vc);
                     }
                 };
                 // (the last iteration carries the next item's raw input in registers instead of the second operand
@@ -462,13 +466,13 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                     fb_waitcnt<nnext>();
                     fb_tie(P[c][0], P[c][1], P[c][2]);
                     if constexpr (dy < 3) fb_tie(K[c][0], K[c][1], K[c][2]);
-                    if constexpr (dy == 0) fb_tie(KB[c]);
-                    st_comp(hf, dy, P[c], K[c], KB[c]);
+                    if constexpr (dy == 0) fb_tie(KB[0]);
+                    st_comp(hf, dy, P[c], K[c], KB[0]);
                     if constexpr (more && I < 2 * KS) {
                         constexpr int hct = I / KS, ks = I % KS;
                         fb_tie(AH[c], AL[c]);
-                        if constexpr (ks == KS - 1) fb_tie(B1[c]);
-                        g1_comp(hct, ks, par ^ 1, AH[c], AL[c], B1[c]);
+                        if constexpr (ks == KS - 1) fb_tie(B1[KS == 1 ? c : 0]);
+                        g1_comp(hct, ks, par ^ 1, AH[c], AL[c], B1[KS == 1 ? c : 0]);
 #pragma unroll
                         for (int k = 0; k < 9; ++k) {
                             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             int it = 0;
             for (; it + 2 < S; it += 2) { iter(P0, T, it); iter(P1, T, it + 1); }
             if (it + 2 == S) { iter(P0, T, it); FB_T(5); iter(P1, F, it + 1); }
-            else { FB_T(5); iter(P0, F, it); }
+            else { FB_T(5); iter(P0, F, it); load_x(min(nitem, a.items - 1)); }
             FB_T(6);
         }
 
@@ -540,6 +544,11 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             store_stage(S - 1);
         } else {
             // -------------------------------------------------------- epilogue: 16-byte stores
+            // (lane geometry from a fresh opaque lane id: kept from the prologue it would sit in registers - or in
+            // scratch - through all the iterations)
+            int t3 = threadIdx.x;
+            asm volatile("" : "+v"(t3));
+            const int r = t3 & 15, ox = tx0 + 16 * (wave & 1) + 4 * ((t3 & 63) >> 4), oy0 = ty0 + 2 * (wave >> 1);
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 const int co = 16 * c + r;

@@ -6,6 +6,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -321,3 +322,30 @@ def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch):
     monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libirm_hip.so")
     with pytest.raises(_hip.HipLibraryError, match="no CPU fallback"):
         _hip.load()
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` outside a launcher starts N ranks through torch.distributed.run (the driver's
+    command shape) instead of exiting; checked without a GPU by intercepting the child process."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("RANK", raising=False)
+    args = bench.parse()
+    assert bench.self_launch(args) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

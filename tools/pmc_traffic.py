@@ -3,7 +3,7 @@
 usage: pmc_traffic.py FETCH_dir WRITE_dir out.json
 FETCH_SIZE / WRITE_SIZE are reported in KiB... checked against a known byte count below; on gfx950
 FETCH_SIZE counts 128-byte requests as 64 bytes, so it is doubled (MI355X_MICROARCH.md, HBM section)."""
-import csv, glob, json, re, sys
+import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 
@@ -34,6 +34,12 @@ for k in sorted(set(fetch) | set(write)):
     r = out[k]
     if r["hbm_read_bytes_per_launch"] is not None and r["hbm_write_bytes_per_launch"] is not None:
         r["hbm_bytes_per_launch"] = r["hbm_read_bytes_per_launch"] + r["hbm_write_bytes_per_launch"]
+import subprocess
+try:
+    out["_git_sha"] = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True,
+                                     cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or os.environ.get("IRM_GIT_SHA")
+except OSError:
+    out["_git_sha"] = os.environ.get("IRM_GIT_SHA")
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-for k, v in sorted(out.items(), key=lambda kv: -(kv[1].get("hbm_bytes_per_launch") or 0) * kv[1]["launches"])[:14]:
+for k, v in sorted(((k, v) for k, v in out.items() if not k.startswith('_')), key=lambda kv: -(kv[1].get("hbm_bytes_per_launch") or 0) * kv[1]["launches"])[:14]:
     print(f"{v['launches']:6d} {(v.get('hbm_read_bytes_per_launch') or 0)/1e6:10.1f} MB rd {(v.get('hbm_write_bytes_per_launch') or 0)/1e6:10.1f} MB wr  {k[:80]}")
