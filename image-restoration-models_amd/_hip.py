@@ -125,6 +125,25 @@ def pack_gemm_weight_split(w: torch.Tensor) -> torch.Tensor:
     return packed.view(-1).view(torch.float32)
 
 
+def split_is_safe(w: torch.Tensor, lnw=None, lnb=None) -> bool:
+    """Range guard of the UNSCALED fp16 hi/lo split used by irm_gemm1x1_f16x3_f32 / irm_dwgemm_f16x3_f32 (the fused
+    branch kernels scale their operands by powers of two instead and need no guard).  False -> the caller keeps
+    that layer on the exact f32-input MFMA entry point.
+      * hi must stay finite with headroom: max|W| < 2^14;
+      * small weights have SUBNORMAL lo parts (the matrix cores do not flush them): a weight is then known to
+        2^-25 absolute instead of 2^-24 relative; max|W| >= 2^-6 keeps the largest weights at 2^-19 relative;
+      * with a LayerNorm prologue the normalised activation must fit fp16: max|ln.weight| sqrt(K) + max|ln.bias| < 2^15."""
+    w = w.detach().reshape(w.shape[0], -1).float()
+    m = float(w.abs().max()) if w.numel() else 0.0
+    if not (m == m) or m >= 2.0 ** 14 or m < 2.0 ** -6:
+        return False
+    if lnw is not None:
+        bound = float(lnw.detach().abs().max()) * (w.shape[1] ** 0.5) + (float(lnb.detach().abs().max()) if lnb is not None else 0.0)
+        if not (bound < 2.0 ** 15):
+            return False
+    return True
+
+
 def pack_conv3x3_weight(w: torch.Tensor) -> torch.Tensor:
     """W [Co][Ci][3][3] -> wp[9][ceil(Co/16)][2*ceil(Ci/8)][64]."""
     w = w.detach().float()

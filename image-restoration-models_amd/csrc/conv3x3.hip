@@ -412,13 +412,7 @@ static int launch_conv_ring(const ConvArgs& a, int B, int ygroups, hipStream_t s
     constexpr int NS = 3;
     constexpr int WU = (9 * CT * 16 + 63) / 64;
     const size_t lds = (size_t)NS * (8 + WU) * 1024;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ring_kernel<CT, NS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return IRM_ELAUNCH;
-        configured = true;
-    }
+    IRM_ALLOW_BIG_LDS((&conv3x3_ring_kernel<CT, NS>));
     const int tiles_y = (a.H + CV_TH - 1) / CV_TH;
     dim3 grid(a.tiles_x * tiles_y, ygroups, B);
     hipLaunchKernelGGL((conv3x3_ring_kernel<CT, NS>), grid, dim3(256), lds, stream, a);
@@ -454,7 +448,7 @@ extern "C" int irm_conv3x3_f32(const float* wp, const float* x, long x_bs, float
     const int nchunks = (a.mtiles + ct - 1) / ct;
     if (ygroups <= 0) ygroups = 1;
     if (ygroups > nchunks) ygroups = nchunks;
-    const bool fast = a.vec && !(x_bs & 3) && irm_aligned16(x) && irm_aligned16(wp) && !getenv("IRM_CONV_GENERIC");
+    const bool fast = a.vec && !(x_bs & 3) && irm_aligned16(x) && irm_aligned16(wp) && !irm_probe_set("IRM_CONV_GENERIC");
     if (fast) {
         switch (ct) {
             case 1: return launch_conv_ring<1>(a, B, ygroups, stream);

@@ -220,7 +220,7 @@ void dwgemm_kernel(DwGemmArgs a) {
         for (int j = 0; j < R; ++j) {
             const float* src = (tail && s >= lim[j]) ? dg_zero_page : base[j];
             base[j] += stride[j];
-            if (!(a.dbg & 1)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            if (!IRM_DBG(a.dbg, 1)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + j * NT * 4), 16, 0, 0);
         }
         if constexpr (F16) {
@@ -281,7 +281,7 @@ void dwgemm_kernel(DwGemmArgs a) {
         asm volatile("s_barrier" ::: "memory");
         if (s + NS - 1 < SL) issue(s + NS - 1);
 
-        if (a.dbg & 2) continue;
+        if (IRM_DBG(a.dbg, 2)) continue;
         const float* xb = smem + (s % NS) * STG;
         const float* wb = xb + XC * 4;
         const v2f* dk = reinterpret_cast<const v2f*>(wb + WC * 4 + g * DWS);
@@ -378,13 +378,7 @@ static int dg_launch(DwGemmArgs a, int B, hipStream_t stream) {
     constexpr int TC = (GATE ? 8 : 4) * 10 * (TW / 4 + 2) + (F16 ? 0 : CT * 16) + (GATE ? 40 : 20);
     constexpr int R = (TC + NT - 1) / NT;
     const size_t lds = (size_t)NS * R * NT * 16 + (F16 ? 2 * CT * 1024 : 0);
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgemm_kernel<CT, GATE, NS, PT, F16, TW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return IRM_ELAUNCH;
-        configured = true;
-    }
+    IRM_ALLOW_BIG_LDS((&dwgemm_kernel<CT, GATE, NS, PT, F16, TW>));
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles = a.tiles_x * ((a.H + 7) / 8);
     const int per = (a.tiles + 7) >> 3;
@@ -407,10 +401,10 @@ static int dwgemm_entry(const float* wp, long w_bs, const float* dwp, const floa
     a.mtiles = (M + 15) / 16; a.ksteps = 4 * ((K + 15) / 16);
     a.tiles_x = (W + 31) / 32;
     a.tiles = a.tiles_x * ((H + 7) / 8);
-    { const char* e = getenv("IRM_DWGEMM_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = irm_probe_int("IRM_DWGEMM_DBG", 0);
     if (split) {
         // 64-wide tiles (IRM_DWGEMM_TW=64): fewer halo sectors, but measured 5-8 % slower than 32-wide ones
-        static const int tw_env = [] { const char* e = getenv("IRM_DWGEMM_TW"); return e ? atoi(e) : 0; }();
+        static const int tw_env = irm_probe_int("IRM_DWGEMM_TW", 0);
         const bool wide = tw_env == 64;
         if (wide) {
             if (a.mtiles <= 3) return gate ? dg_launch<3, true, 4, true, 64>(a, B, stream) : dg_launch<3, false, 4, true, 64>(a, B, stream);
@@ -419,7 +413,7 @@ static int dwgemm_entry(const float* wp, long w_bs, const float* dwp, const floa
         if (a.mtiles <= 3) return gate ? dg_launch<3, true, 4, true>(a, B, stream) : dg_launch<3, false, 4, true>(a, B, stream);
         return gate ? dg_launch<6, true, 4, true>(a, B, stream) : dg_launch<6, false, 4, true>(a, B, stream);
     }
-    static const int pt_env = [] { const char* e = getenv("IRM_DWGEMM_PT"); return e ? atoi(e) : 0; }();
+    static const int pt_env = irm_probe_int("IRM_DWGEMM_PT", 0);
     const int pt = pt_env == 2 ? 2 : 4;      // 8 waves x 2 pixels: twice the occupancy, measured no faster
     if (a.mtiles <= 3) {
         if (pt == 4) return gate ? dg_launch<3, true, 4>(a, B, stream) : dg_launch<3, false, 4>(a, B, stream);

@@ -244,6 +244,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
         // ------------------------------------------------------------ resident input: LayerNorm + fp16 split
         fb_h8 xh[3][KS], xl[3][KS];
         bool inside[3];
+        float osc[3];                              // per pixel: 1 / (operand scales) of the project_in accumulators
         {
             const float invC = 1.0f / (float)a.C;
             const bool wb = a.ln_mode == IRM_LN_WITHBIAS;
@@ -274,7 +275,14 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                     }
                 q += __shfl_xor(q, 16);
                 q += __shfl_xor(q, 32);
-                const float rs = 16.0f / sqrtf(q * invC + a.eps);          // operands carry a factor 2^4
+                // The fp16 operand is the input normalised to UNIT RMS (x 2^4), whatever eps does to the LayerNorm
+                // output: where var << eps (near-constant or tiny inputs) LN(x) is tiny and its lo part would fall
+                // into the fp16 subnormals.  The remaining factor rms / sqrt(var + eps) <= 1 is applied in fp32 to the
+                // accumulator of this pixel (osc[j]).
+                const float var = q * invC;
+                const float ms = wb ? var : fmaf(mean, mean, var);         // mean square of the operand (d or x)
+                const float rs = ms > 0.f ? 16.0f / sqrtf(ms) : 0.f;
+                osc[j] = a.inv_s1 * sqrtf(ms / (var + a.eps));
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                 for (int j = 0; j < 3; ++j) {
                     f32x4 h;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = inside[j] ? fmaf(acc1[j][e], a.inv_s1, b1[e]) : 0.f;
+                    for (int e = 0; e < 4; ++e) h[e] = inside[j] ? fmaf(acc1[j][e], osc[j], b1[e]) : 0.f;
                     fb_st<f32x4>(lds, vq[j], img * PL_B + hct * 64, h);
                 }
             }

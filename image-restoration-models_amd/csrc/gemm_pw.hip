@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
     const bool ragged = (a.K % BK) != 0;                       // only then can a row index pass K - 1
 
     auto issue = [&](int it) {
-        if (a.dbg & 1) return;
+        if (IRM_DBG(a.dbg, 1)) return;
         const int ci = it / S, s = it - ci * S;
         const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
         float* xb = smem + (it % NS) * STG;
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
 #pragma unroll
                 for (int p = 0; p < PT; ++p) {
                     // masked lanes write a dump slot so that exactly NST store instructions are issued
-                    float4* dst = (row_ok && pixs[p] < a.N && !(a.dbg & 2))
+                    float4* dst = (row_ok && pixs[p] < a.N && !IRM_DBG(a.dbg, 2))
                         ? reinterpret_cast<float4*>(Y + (long)co * a.N + pixs[p])
                         : irm_dump + ((blockIdx.x & 255) * 64 + lane);
                     *dst = make_float4(acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]);
@@ -545,13 +545,7 @@ static int launch_ring(const GemmArgs& a, int B, int ygroups, hipStream_t stream
     constexpr int NS = PT == 2 ? 4 : 3;
     constexpr int BN = 64 * PT;
     const size_t lds = ((size_t)NS * (16 * BN + CT * 256) + 2 * (size_t)a.ksteps * 4) * sizeof(float);
-    static bool configured = false;              // per instantiation
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<PT, CT, NS, LN, RES, F16>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return IRM_ELAUNCH;
-        configured = true;
-    }
+    IRM_ALLOW_BIG_LDS((&gemm_ring_kernel<PT, CT, NS, LN, RES, F16>));
     dim3 grid((a.N + BN - 1) / BN, ygroups, B);
     hipLaunchKernelGGL((gemm_ring_kernel<PT, CT, NS, LN, RES, F16>), grid, dim3(256), lds, stream, a);
     return irm_launch_status();
@@ -583,7 +577,7 @@ static int launch_ring_split(const GemmArgs& a, int B, int ygroups, hipStream_t 
         if (a.ln_mode != IRM_LN_NONE) return IRM_EINVAL;
         return launch_ring<2, CT, IRM_LN_NONE, true, true>(a, B, ygroups, stream);
     }
-    static const int pt = [] { const char* e = getenv("IRM_GEMM_SPLIT_PT"); return e ? atoi(e) : 4; }();
+    static const int pt = irm_probe_int("IRM_GEMM_SPLIT_PT", 4);
     if (pt == 2) {
         if (a.ln_mode == IRM_LN_WITHBIAS) return launch_ring<2, CT, IRM_LN_WITHBIAS, false, true>(a, B, ygroups, stream);
         if (a.ln_mode == IRM_LN_BIASFREE) return launch_ring<2, CT, IRM_LN_BIASFREE, false, true>(a, B, ygroups, stream);
@@ -606,7 +600,7 @@ static int launch_gemm(const GemmArgs& a, int B, int ygroups, bool vec, hipStrea
 // ---------------------------------------------------------------------------
 // C ABI (declared in include/irm_hip.h)
 static bool irm_force_generic() {
-    static const bool v = getenv("IRM_GEMM_GENERIC") != nullptr;   // A/B switch for benchmarking only
+    static const bool v = irm_probe_set("IRM_GEMM_GENERIC");   // A/B switch for benchmarking only
     return v;
 }
 // gemm_xres.hip: input-resident variant of the emulated GEMM for K <= 96
@@ -631,7 +625,7 @@ static int gemm_entry(const float* wp, long w_bs, const float* x, long x_bs, flo
     a.bias = bias; a.stats = stats; a.lnw = lnw; a.lnb = lnb; a.rscale = res ? res_scale : nullptr;
     a.M = M; a.K = K; a.N = N; a.mtiles = (M + 15) / 16; a.ksteps = 4 * ((K + 15) / 16);
     a.ln_mode = ln_mode; a.act = act; a.stats_out = stats_out; a.eps = eps;
-    a.dbg = getenv("IRM_GEMM_DBG") ? atoi(getenv("IRM_GEMM_DBG")) : 0;
+    a.dbg = irm_probe_int("IRM_GEMM_DBG", 0);
     // fused output statistics need every output channel in one workgroup pass
     if (stats_out && (ct <= 0 || a.mtiles > ct)) return IRM_EINVAL;
     const int nchunks = (a.mtiles + (ct > 0 ? ct : 1) - 1) / (ct > 0 ? ct : 1);
@@ -641,7 +635,7 @@ static int gemm_entry(const float* wp, long w_bs, const float* x, long x_bs, flo
     if (split) {
         // weights packed by the caller as fp16 hi/lo pairs: only the ring kernel understands them
         if (!vec || N < 4 || (res && ln_mode != IRM_LN_NONE)) return IRM_EINVAL;
-        static const bool no_xres = getenv("IRM_GEMM_NO_XRES") != nullptr;
+        static const bool no_xres = irm_probe_set("IRM_GEMM_NO_XRES");
         if (K <= 192 && ln_mode != IRM_LN_NONE && !stats_out && !res && !w_bs && !no_xres && B <= 65535 && (long)(N + 127) / 128 <= 2147483647L) {
             const int rc = irm_gemm_xres_dispatch(wp, x, x_bs, y, y_bs, bias, stats, lnw, lnb, ln_mode, act, B, M, K, N, stream);
             if (rc != IRM_EINVAL) return rc;
@@ -659,7 +653,7 @@ static int gemm_entry(const float* wp, long w_bs, const float* x, long x_bs, flo
         // 64 pixels per wave (PT 4) doubles the MFMAs per barrier; it is used when the accumulators
         // (+ the prefetched residual) still fit 2 waves per SIMD and the grid stays large
         int pt = (!res && (long)B * ((N + 255) / 256) * ygroups >= 512) ? 4 : 2;
-        if (const char* e = getenv("IRM_GEMM_PT")) pt = atoi(e);
+        pt = irm_probe_int("IRM_GEMM_PT", pt);
         switch (ct) {
             case 3: return launch_ring_any<3>(a, B, ygroups, pt, stream);
             case 4: return launch_ring_any<4>(a, B, ygroups, pt, stream);

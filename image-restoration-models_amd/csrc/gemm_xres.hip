@@ -68,7 +68,7 @@ __global__ __launch_bounds__((NPT / WP + 1) * 64, 1) void gemm_xres_kernel(XresA
     float* Y = a.Y + (long)b * a.y_bs;
 
     const int nchunks = (a.mtiles + CT - 1) / CT;
-    const int TOT = (a.dbg & 2) ? 0 : nchunks * KP;
+    const int TOT = IRM_DBG(a.dbg, 2) ? 0 : nchunks * KP;
 
     if (a.ln_mode != IRM_LN_NONE) {
         for (int k = tid; k < 16 * KT; k += (NW + 1) * 64) {
@@ -111,7 +111,7 @@ __global__ __launch_bounds__((NPT / WP + 1) * 64, 1) void gemm_xres_kernel(XresA
     // ---------------------------------------------------------------------- compute waves
     // resident input: thread = (pixel, half of the channel-quad groups); channel of k-slot (g, j) of stage s
     // is 16 s + 4 j + g (the order the weights are packed in)
-    if (!(a.dbg & 1)) {
+    if (!IRM_DBG(a.dbg, 1)) {
         const int px = tid % BN, par = tid / BN;
         const int n = min(n0 + px, a.N - 1);
         float mean = 0.f, rstd = 1.f;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__((NPT / WP + 1) * 64, 1) void gemm_xres_kernel(XresA
                     if (a.act != IRM_ACT_NONE) {
                         v.x = xr_act(v.x, a.act); v.y = xr_act(v.y, a.act); v.z = xr_act(v.z, a.act); v.w = xr_act(v.w, a.act);
                     }
-                    if (row_ok && pixs[p] < a.N && !(a.dbg & 4)) *reinterpret_cast<float4*>(Y + (long)co * a.N + pixs[p]) = v;
+                    if (row_ok && pixs[p] < a.N && !IRM_DBG(a.dbg, 4)) *reinterpret_cast<float4*>(Y + (long)co * a.N + pixs[p]) = v;
                     acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
@@ -228,13 +228,7 @@ __global__ __launch_bounds__((NPT / WP + 1) * 64, 1) void gemm_xres_kernel(XresA
 template <int KT, int CT, int NS = 3, int NPT = 16, int WP = 2>
 static int xres_launch(const XresArgs& a, int B, hipStream_t stream) {
     const size_t lds = ((size_t)2 * KT * NPT * 128 + (size_t)NS * CT * 512 + 32 * KT) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xres_kernel<KT, CT, NS, WP, NPT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return IRM_ELAUNCH;
-        configured = true;
-    }
+    IRM_ALLOW_BIG_LDS((&gemm_xres_kernel<KT, CT, NS, WP, NPT>));
     hipLaunchKernelGGL((gemm_xres_kernel<KT, CT, NS, WP, NPT>), dim3((a.N + NPT * 16 - 1) / (NPT * 16), 1, B),
                        dim3((NPT / WP + 1) * 64), lds, stream, a);
     return irm_launch_status();
@@ -247,14 +241,14 @@ int irm_gemm_xres_dispatch(const float* wp, const float* x, long x_bs, float* y,
     XresArgs a;
     a.Wp = wp; a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.bias = bias; a.stats = stats; a.lnw = lnw; a.lnb = lnb;
     a.M = M; a.K = K; a.N = N; a.mtiles = (M + 15) / 16; a.stages = (K + 15) / 16; a.ln_mode = ln_mode; a.act = act;
-    { const char* e = getenv("IRM_XRES_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = irm_probe_int("IRM_XRES_DBG", 0);
     // tiles per pass: 9 when it divides the tile count (144, 288 channels), else 8
     const bool nine = a.mtiles % 9 == 0;
     switch (a.stages) {
         case 2: return nine ? xres_launch<2, 9>(a, B, stream) : xres_launch<2, 8>(a, B, stream);
         case 4: return nine ? xres_launch<4, 9>(a, B, stream) : xres_launch<4, 8>(a, B, stream);
         case 6:
-            if (getenv("IRM_XRES_DEEP")) return xres_launch<6, 4, 6>(a, B, stream);      // experiment: 4-tile stages, 6-deep ring
+            if (irm_probe_set("IRM_XRES_DEEP")) return xres_launch<6, 4, 6>(a, B, stream);      // experiment: 4-tile stages, 6-deep ring
             return nine ? xres_launch<6, 9>(a, B, stream) : xres_launch<6, 8>(a, B, stream);
         case 12:
             if (M < 512) return IRM_EINVAL;      // few output tiles per converted input: the streaming kernel is faster

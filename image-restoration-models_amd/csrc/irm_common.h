@@ -20,6 +20,34 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define IRM_LN_WITHBIAS 1
 #define IRM_LN_BIASFREE 2
 
+// Experiment switches (environment variables that select kernel variants, timing-only modes that skip work) exist only
+// in -DIRM_PROBES builds (tools/build_variant.sh); in the product build they are compile-time constants: no environment
+// variable can change what a kernel computes or skip part of it.
+#ifdef IRM_PROBES
+#include <stdlib.h>
+static inline int irm_probe_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline bool irm_probe_set(const char* name) { return getenv(name) != nullptr; }
+#define IRM_DBG(v, bit) (((v) & (bit)) != 0)
+#else
+static inline int irm_probe_int(const char*, int dflt) { return dflt; }
+static inline bool irm_probe_set(const char*) { return false; }
+#define IRM_DBG(v, bit) false
+#endif
+
+// Kernels that use more than 64 KiB of LDS: raise the limit once per (kernel instantiation, device).
+#define IRM_ALLOW_BIG_LDS(kernel_ptr)                                                                              \
+    do {                                                                                                           \
+        static unsigned char irm_done_[64] = {0};                                                                  \
+        int irm_dev_ = 0;                                                                                          \
+        if (hipGetDevice(&irm_dev_) != hipSuccess || irm_dev_ < 0 || irm_dev_ >= 64) return IRM_ELAUNCH;           \
+        if (!irm_done_[irm_dev_]) {                                                                                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_ptr),                                     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)         \
+                return IRM_ELAUNCH;                                                                                \
+            irm_done_[irm_dev_] = 1;                                                                               \
+        }                                                                                                          \
+    } while (0)
+
 static inline int irm_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? IRM_OK : IRM_ELAUNCH;

@@ -291,13 +291,7 @@ template <int T>
 static int launch_gram_ring(const GramArgs& a, int B, hipStream_t stream) {
     constexpr int NS = 3;
     const size_t lds = (size_t)NS * 24 * 1024;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mdta_gram_ring_kernel<T, NS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return IRM_ELAUNCH;
-        configured = true;
-    }
+    IRM_ALLOW_BIG_LDS((&mdta_gram_ring_kernel<T, NS>));
     hipLaunchKernelGGL((mdta_gram_ring_kernel<T, NS>), dim3(a.heads * a.nchunk, B), dim3(256), lds, stream, a);
     return irm_launch_status();
 }
@@ -311,7 +305,7 @@ extern "C" int irm_mdta_gram_f32(const float* qkv, long bs, float* part, int B, 
     GramArgs a{qkv, bs, part, C, heads, N, chunk, (N + chunk - 1) / chunk};
     const bool aligned = !(N & 3) && !(bs & 3) && irm_aligned16(qkv);
     if (aligned && !(N & 63) && (c == 48 || c == 96) && (long)heads * a.nchunk <= 2147483647L &&
-        !getenv("IRM_GRAM_GENERIC"))
+        !irm_probe_set("IRM_GRAM_GENERIC"))
         return c == 48 ? launch_gram_ring<3>(a, B, stream) : launch_gram_ring<6>(a, B, stream);
     const int sb = (c % 48 == 0) ? 3 : (c % 32 == 0) ? 2 : 1;
     const int nsb = c / (16 * sb);

@@ -12,8 +12,9 @@ import numpy as _np
 import torch as _torch
 
 from .models.fpn_mobilenet import FPNMobileNet  # noqa: E402
+from .models.fpn_inception import FPNInceptionDecoder  # noqa: E402
 
-__all__ = ["FPNMobileNet", "get_model", "normalize", "pad", "postprocess", "SYNTH_RULES"]
+__all__ = ["FPNMobileNet", "FPNInceptionDecoder", "get_model", "normalize", "pad", "postprocess", "SYNTH_RULES"]
 
 
 def normalize(x: _np.ndarray):
@@ -39,8 +40,10 @@ def get_model(weights_path: str, device: _torch.device):
     DataParallel 'module.' prefix; the model is returned in TRAIN mode like the reference."""
     name = _os.path.basename(weights_path).split('.')[0]
     if name != 'fpn_mobilenet':
-        raise NotImplementedError(f"generator {name!r}: only fpn_mobilenet is built in the MI355X path (fpn_inception's "
-                                  "backbone lives in timm, which is not vendored in the reference)")
+        raise NotImplementedError(f"generator {name!r}: only fpn_mobilenet is built end to end in the MI355X path.  "
+                                  "fpn_inception's encoder is timm's InceptionResNetV2 (third-party, not vendored in the "
+                                  "reference, absent here); its in-tree decoder is deblurganv2.FPNInceptionDecoder, which "
+                                  "takes the encoder's five feature maps as inputs")
     model = FPNMobileNet()
     sd = _torch.load(weights_path, map_location="cpu", weights_only=True)['model']
     model.load_state_dict({(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()})

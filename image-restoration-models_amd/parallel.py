@@ -12,12 +12,20 @@ def shard_image_ids(n_images: int, rank: int, world: int) -> list:
     return list(range(rank, n_images, world))
 
 
-def gather_results(elapsed_s: float, rows, device):
+def gather_results(elapsed_s: float, rows, device, failed_ids=None):
     """rows: list of (image_id, value...) floats of this rank.  Returns (max elapsed over ranks,
-    float64 tensor of all ranks' rows, rank-major).  Works without an initialised process group."""
+    float64 tensor of all ranks' rows, rank-major).  Works without an initialised process group.
+    failed_ids (optional): ids of the images this rank could not process (a frame that raised, SURVEY section 5);
+    when given, a third value is returned: the sorted ids of all ranks' failures, so that rank 0 can report
+    which images are missing from the table instead of silently averaging over fewer."""
     import torch.distributed as dist
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
-    r = torch.tensor(rows, dtype=torch.float64, device=device).reshape(len(rows), -1)
+    r = (torch.tensor(rows, dtype=torch.float64, device=device).reshape(len(rows), -1) if len(rows)
+         else torch.zeros(0, 2, dtype=torch.float64, device=device))
+    if failed_ids is not None:
+        t2, ftab = gather_results(elapsed_s, [(float(i), 0.0) for i in failed_ids], device)
+        t3, table = gather_results(elapsed_s, rows, device)
+        return max(t2, t3), table, sorted(int(v) for v in ftab[:, 0].tolist()) if ftab.numel() else []
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(t.item()), r.cpu()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

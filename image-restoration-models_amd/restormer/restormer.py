@@ -188,9 +188,15 @@ class Restormer(nn.Module):
                     pout=_hip.pack_gemm_weight(ff.project_out.weight), pout_b=f32(ff.project_out.bias),
                     n1w=f32(m.norm1.w), n1b=f32(m.norm1.b), n2w=f32(m.norm2.w), n2b=f32(m.norm2.b))
                 if self._split:
-                    pk[name].update(qkv_s=_hip.pack_gemm_weight_split(a.qkv.weight),
-                                    pin_s=_hip.pack_gemm_weight_split(ff.project_in.weight),
-                                    pout_s=_hip.pack_gemm_weight_split(ff.project_out.weight))
+                    # per layer: outside the safe range of the unscaled split (trained checkpoints with large LayerNorm
+                    # gains or tiny / huge weights) the layer stays on the exact f32 MFMA (_hip.split_is_safe)
+                    if _hip.split_is_safe(a.qkv.weight, m.norm1.w, m.norm1.b):
+                        pk[name]["qkv_s"] = _hip.pack_gemm_weight_split(a.qkv.weight)
+                    if _hip.split_is_safe(ff.project_in.weight, m.norm2.w, m.norm2.b):
+                        pk[name]["pin_s"] = _hip.pack_gemm_weight_split(ff.project_in.weight)
+                    if _hip.split_is_safe(ff.project_out.weight):
+                        pk[name]["pout_s"] = _hip.pack_gemm_weight_split(ff.project_out.weight)
+                    pk[name]["mfold_split"] = _hip.split_is_safe(a.project_out.weight)
                 if self._split and ops.can_fuse_gdfn(m.dim, 4):
                     # whole-branch kernels (fused_block.hip): LN + qkv + dwconv, and the complete GDFN
                     pk[name].update(
@@ -257,8 +263,10 @@ class Restormer(nn.Module):
         if not have_stats:
             ops.ln_stats(x, stats)
         split = self._split and N % 4 == 0            # the emulation kernel needs the 16-byte fast path
-        ops.gemm1x1(w["qkv_s" if split else "qkv"], x, qkv, 3 * C, C, bias=w["qkv_b"], stats=stats, lnw=w["n1w"],
-                    lnb=w["n1b"], ln_mode=blk.norm1.mode, split=split)
+        s_qkv, s_pin, s_pout = split and "qkv_s" in w, split and "pin_s" in w, split and "pout_s" in w
+        s_fold = split and w.get("mfold_split", False)
+        ops.gemm1x1(w["qkv_s" if s_qkv else "qkv"], x, qkv, 3 * C, C, bias=w["qkv_b"], stats=stats, lnw=w["n1w"],
+                    lnb=w["n1b"], ln_mode=blk.norm1.mode, split=s_qkv)
         fuse_dw = "v_dwp" in w and ops.can_fuse_dw(C, W) and not os.environ.get("IRM_NO_FUSE_DW")
         if fuse_dw:
             # q, k only: the depth-wise conv of v happens inside the apply GEMM below
@@ -276,28 +284,28 @@ class Restormer(nn.Module):
             mfold = torch.zeros(B * mfold_n, dtype=torch.float32, device=dev)
             ws[("mfold", C, B)] = mfold
         # the folded per-image matrix in the order of the kernel that applies it (fp16 hi/lo when emulated)
-        ops.mdta_fold(qkv2, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=split)
+        ops.mdta_fold(qkv2, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=s_fold)
         if fuse_dw:
             ops.dwgemm(mfold, w["v_dwp"], qkv[:, 2 * C:], x, C, C, gate=False, res=x, bias=w["wout_b"],
-                       w_bs=mfold_n, stats_out=stats if fuse else None, split=split)
+                       w_bs=mfold_n, stats_out=stats if fuse else None, split=s_fold)
         else:
             ops.gemm1x1(mfold, qkv2[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n,
-                        stats_out=stats if fuse else None, split=split)
+                        stats_out=stats if fuse else None, split=s_fold)
         # --- feed-forward branch: x += project_out(gelu(dw(h1)) * dw(h2))   (restormer.py:88-93, 148)
         h = big_a[:B * 2 * hid * N].view(B, 2 * hid, H, W)
         g = big_b[:B * hid * N].view(B, hid, H, W)
         if not fuse:
             ops.ln_stats(x, stats)
-        ops.gemm1x1(w["pin_s" if split else "pin"], x, h, 2 * hid, C, bias=w["pin_b"], stats=stats, lnw=w["n2w"],
-                    lnb=w["n2b"], ln_mode=blk.norm2.mode, split=split)
+        ops.gemm1x1(w["pin_s" if s_pin else "pin"], x, h, 2 * hid, C, bias=w["pin_b"], stats=stats, lnw=w["n2w"],
+                    lnb=w["n2b"], ln_mode=blk.norm2.mode, split=s_pin)
         emit = fuse and want_stats
         if fuse_dw:
-            ops.dwgemm(w["pout_s" if split else "pout"], w["ffn_dwp"], h, x, C, hid, gate=True, res=x,
-                       bias=w["pout_b"], stats_out=stats if emit else None, split=split)
+            ops.dwgemm(w["pout_s" if s_pout else "pout"], w["ffn_dwp"], h, x, C, hid, gate=True, res=x,
+                       bias=w["pout_b"], stats_out=stats if emit else None, split=s_pout)
         else:
             ops.dwconv3x3_gate(h, w["ffn_dw"], g, bias=w["ffn_dw_b"])
-            ops.gemm1x1(w["pout_s" if split else "pout"], g, x, C, hid, res=x, bias=w["pout_b"],
-                        stats_out=stats if emit else None, split=split)
+            ops.gemm1x1(w["pout_s" if s_pout else "pout"], g, x, C, hid, res=x, bias=w["pout_b"],
+                        stats_out=stats if emit else None, split=s_pout)
         return emit
 
     def _block_fused(self, blk: TransformerBlock, w: dict, x: torch.Tensor, alt: torch.Tensor) -> torch.Tensor:
@@ -321,8 +329,9 @@ class Restormer(nn.Module):
         if mfold is None or mfold.device != dev:
             mfold = torch.zeros(B * mfold_n, dtype=torch.float32, device=dev)
             ws[("mfold", C, B)] = mfold
-        ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=True)
-        ops.gemm1x1(mfold, qkv[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n, split=True)
+        s_fold = w.get("mfold_split", False)
+        ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=s_fold)
+        ops.gemm1x1(mfold, qkv[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n, split=s_fold)
         ops.gdfn_fused(w["gdfn_f"], x, alt, C, hid, ln_mode=blk.norm2.mode, bias=w["pout_b"])
         return alt
 

@@ -12,8 +12,12 @@
  *    planar NCHW: element (b, c, n) of a tensor with batch stride `bs` (in
  *    elements) lives at base[b*bs + c*N + n], N = H*W.  Batch strides let a
  *    kernel read / write a channel slice of a larger (concat) buffer.
- *  - no allocation, no host synchronisation, no global state inside: all work
- *    is enqueued on `stream` (a hipStream_t), workspaces are passed in.
+ *  - no allocation, no host synchronisation inside: all work is enqueued on
+ *    `stream` (a hipStream_t), workspaces are passed in.  The only state the
+ *    library keeps is a per-(kernel, device) flag "the >64 KiB LDS limit has
+ *    been raised" and read-only device constants (a zero page for border
+ *    loads, a dump page for masked stores).  No environment variable is read
+ *    in the product build (experiment switches exist only under -DIRM_PROBES).
  *  - return value: 0 = enqueued, IRM_EINVAL (-1) = rejected arguments (nothing
  *    launched), IRM_ELAUNCH (-2) = the HIP launch failed.
  *  - packed weights ("wp"): MFMA B-operand order produced on the host,

@@ -99,3 +99,33 @@ def pad32(x: torch.Tensor) -> torch.Tensor:
 
 def postprocess(x: torch.Tensor) -> torch.Tensor:
     return (x + 1) / 2.0
+
+
+def fpn_inception_decoder(x, encs, p):
+    """FPN-Inception WITHOUT its timm encoder: FPN.forward's lateral / reflect-pad / top-down path
+    (src/deblurganv2/models/fpn_inception.py:153-170) and FPNInception.forward's heads, smoothing and output
+    (:65-81) on given encoder maps encs = (enc0..enc4); InstanceNorm2d(affine=False) in train mode.  Pinned by
+    oracle/gen_golden.py --only fpn_inception against the reference class with constant-output encoder stages."""
+    e0, e1, e2, e3, e4 = encs
+    lat = lambda i, e: F.conv2d(e, p[f"fpn.lateral{i}.weight"])            # noqa: E731
+    l4 = F.pad(lat(4, e4), (1, 1, 1, 1), "reflect")
+    l3 = F.pad(lat(3, e3), (1, 1, 1, 1), "reflect")
+    l2 = F.pad(lat(2, e2), (1, 2, 1, 2), "reflect")
+    l1 = F.pad(lat(1, e1), (1, 1, 1, 1), "reflect")
+    map0 = F.pad(lat(0, e0), (0, 1, 0, 1), "reflect")
+    up = lambda t, s: F.interpolate(t, scale_factor=s, mode="nearest")     # noqa: E731
+    td = lambda n, t: F.relu(_inorm(F.conv2d(t, p[f"fpn.{n}.0.weight"], p[f"fpn.{n}.0.bias"], padding=1)))   # noqa: E731
+    map4 = l4
+    map3 = td("td1", l3 + up(map4, 2))
+    map2 = td("td2", l2 + up(map3, 2))
+    map1 = td("td3", l1 + up(map2, 2))
+
+    def head(i, t):
+        t = F.relu(F.conv2d(t, p[f"head{i}.block0.weight"], padding=1))
+        return F.relu(F.conv2d(t, p[f"head{i}.block1.weight"], padding=1))
+    cat = torch.cat([up(head(4, map4), 8), up(head(3, map3), 4), up(head(2, map2), 2), head(1, map1)], dim=1)
+    sm = F.relu(_inorm(F.conv2d(cat, p["smooth.0.weight"], p["smooth.0.bias"], padding=1)))
+    sm = up(sm, 2)
+    sm = F.relu(_inorm(F.conv2d(sm + map0, p["smooth2.0.weight"], p["smooth2.0.bias"], padding=1)))
+    sm = up(sm, 2)
+    return torch.clamp(torch.tanh(F.conv2d(sm, p["final.weight"], p["final.bias"], padding=1)) + x, -1, 1)

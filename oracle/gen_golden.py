@@ -14,7 +14,7 @@ What it does
      the max-abs differences in tests/golden/MANIFEST.json;
   3. stores the REFERENCE outputs (not the oracle's) as golden vectors.
 
-Usage: python oracle/gen_golden.py [--only restormer|tiler|convnets|ops|deblurgan|fullsize|demo|mair]
+Usage: python oracle/gen_golden.py [--only restormer|tiler|convnets|ops|deblurgan|fpn_inception|fullsize|fullsize_c3|fullsize_c5|demo|mair]
 """
 from __future__ import annotations
 
@@ -453,6 +453,74 @@ def gen_deblurgan(ref, manifest):
     np.savez_compressed(os.path.join(GOLD, "deblurgan.npz"), **out)
 
 
+def gen_fpn_inception(ref, manifest):
+    """FPN-Inception decoder: the reference's own fpn_inception.py (FPNInception + FPN classes) with `timm` /
+    `torchsummary` stubbed (absent third-party packages) and the five encoder stages replaced by modules that return
+    fixed synthetic feature maps, so that everything the reference itself defines - laterals, reflect pads, top-down
+    path, heads, smoothing, output - runs unmodified.  The encoder's arithmetic (timm InceptionResNetV2) stays
+    unpinned."""
+    import functools
+    import importlib
+    import torch.nn as nn
+    from irm_amd.deblurganv2 import SYNTH_RULES as DG_RULES
+    base = "/root/reference/src/deblurganv2"
+    for k in [k for k in sys.modules if k == "deblurganv2" or k.startswith("deblurganv2.")]:
+        del sys.modules[k]
+    for name, path in (("deblurganv2", base), ("deblurganv2.models", base + "/models")):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        sys.modules[name] = m
+
+    class _Backbone(nn.Module):                       # what timm.create_model returns, as far as FPN.__init__ touches it
+        def __init__(self):
+            super().__init__()
+            for n in ("conv2d_1a", "conv2d_2a", "conv2d_2b", "maxpool_3a", "conv2d_3b", "conv2d_4a", "maxpool_5a",
+                      "mixed_5b", "repeat", "mixed_6a", "repeat_1", "mixed_7a", "classif"):
+                setattr(self, n, nn.Identity())
+    timm = types.ModuleType("timm")
+    timm.create_model = lambda *a, **k: _Backbone()
+    ts = types.ModuleType("torchsummary")
+    ts.summary = lambda *a, **k: None
+    sys.modules["timm"], sys.modules["torchsummary"] = timm, ts
+    fi = importlib.import_module("deblurganv2.models.fpn_inception")
+    norm = functools.partial(nn.InstanceNorm2d, affine=False, track_running_stats=True)     # networks.py:22
+    net = fi.FPNInception(norm_layer=norm)
+    net.train(True)
+
+    class _Const(nn.Module):
+        def __init__(self, t):
+            super().__init__()
+            self.t = t
+
+        def forward(self, _):
+            return self.t
+    params = {k: tuple(v.shape) for k, v in net.state_dict().items()
+              if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+    manifest["fpn_inception_decoder_param_shapes"] = {k: list(v) for k, v in params.items()}
+    sd = synth.synth_state_dict(params, seed=42, rules=DG_RULES)
+    net.load_state_dict(sd, strict=False)
+    out = {}
+    chans = (32, 64, 192, 1088, 2080)
+    # encoder map sizes of InceptionResNetV2 for an H x W input: H/2-1, H/4-2, H/8-3, H/16-2, H/32-2 (H = 256: 127, 62, 29, 14, 6)
+    for (h, w) in [(128, 160), (256, 128)]:
+        sizes = [(h // 2 - 1, w // 2 - 1), (h // 4 - 2, w // 4 - 2), (h // 8 - 3, w // 8 - 3), (h // 16 - 2, w // 16 - 2),
+                 (h // 32 - 2, w // 32 - 2)]
+        x = synth_input(f"fi_in_{h}x{w}", (1, 3, h, w), -1.0, 1.0)
+        encs = [synth_input(f"fi_enc{i}_{h}x{w}", (1, chans[i]) + sizes[i], -1.0, 1.0) for i in range(5)]
+        for i in range(5):
+            setattr(net.fpn, f"enc{i}", _Const(encs[i]))
+        with torch.no_grad():
+            y_ref = net(x)
+            y_orc = deblurgan_ref.fpn_inception_decoder(x, encs, sd)
+        d = maxabs(y_ref, y_orc)
+        manifest.setdefault("oracle_vs_reference", {})[f"fpn_inception_decoder/{h}x{w}"] = d
+        print(f"fpn_inception decoder {h}x{w}: oracle-vs-reference {d:.3e} |y-x| mean {float((y_ref - x).abs().mean()):.4f}")
+        assert d <= 2e-5
+        out[f"fi_{h}x{w}"] = y_ref.numpy()
+        out[f"fi_sizes_{h}x{w}"] = np.array(sizes, dtype=np.int32)
+    np.savez_compressed(os.path.join(GOLD, "fpn_inception.npz"), **out)
+
+
 def gen_fullsize(ref, manifest):
     """BASELINE.json configs[3] (the headline workload) at its full tile size: the reference Restormer (motion-deblur configuration,
     synthetic weights seed 42) on tile 0 (512x512) of the benchmark's first synthetic 1280x720 frame.  The
@@ -475,6 +543,54 @@ def gen_fullsize(ref, manifest):
                         row100=y[:, 100, :], in_sha=np.frombuffer(bytes.fromhex(sha(x.numpy())), dtype=np.uint8))
     manifest["restormer_fullsize"] = {"input": "synth_image_pair(0,720,1280,3,seed_base=1000,blur=15)[0][:512,:512]/255",
                                       "config": "deblur_withbias", "weights_seed": 42}
+
+
+def gen_fullsize_c3(ref, manifest):
+    """BASELINE.json configs[2] (Restormer colour blind-denoise, BiasFree LayerNorm) at its full tile size: the
+    reference model on tile 0 (256x256, PATCH_CONFIG denoising) of a 512x512 synthetic frame with sigma = 25 noise
+    (seed 0, as run_model_inference adds it).  Fixture: every 4th output pixel + one row + moments (50 KB)."""
+    from irm_amd.restormer import restormer as prod
+    net = ref.rmod.Restormer(**RESTORMER_CFGS["denoise_biasfree"]).eval()
+    sd = synth.synth_state_dict(shapes_of(net), seed=42, rules=prod.SYNTH_RULES)
+    net.load_state_dict(sd, strict=True)
+    inp, _ = synth.synth_image_pair(3, 512, 512, 3, seed_base=1000, blur=0)
+    x01 = inp[:256, :256].astype(np.float32) / 255.0
+    rng = np.random.RandomState(0)
+    x01 = x01 + rng.normal(0, 25 / 255.0, x01.shape).astype(np.float32)       # (src/utils.py:386-389 shape of the noise step)
+    x = torch.from_numpy(np.ascontiguousarray(x01.transpose(2, 0, 1)))[None].float()
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        y = net(x)[0].numpy()
+    print(f"fullsize c3: reference BiasFree forward on 1x3x256x256 took {time.time() - t0:.0f} s; range [{y.min():.3f},{y.max():.3f}]")
+    np.savez_compressed(os.path.join(GOLD, "restormer_fullsize_c3.npz"), x=x[0].numpy().astype(np.float32), sub4=y[:, ::4, ::4],
+                        mean=y.mean(axis=(1, 2)), sqmean=(y.astype(np.float64) ** 2).mean(axis=(1, 2)), row77=y[:, 77, :])
+    manifest["restormer_fullsize_c3"] = {"config": "denoise_biasfree", "weights_seed": 42,
+                                         "input": "stored in the fixture (tile 0 of synth frame 3 + N(0, 25/255), RandomState(0))"}
+
+
+def gen_fullsize_c5(ref, manifest):
+    """BASELINE.json configs[4] (MaIRUNet real-denoise) at its full tile size 256x256: the reference's own
+    mairunet_arch.MaIRUNet (scan op = oracle stand-in, as everywhere: mamba_ssm is absent) - scan length
+    L = 65 536 at level 1.  Fixture: every 4th output pixel + one row + moments."""
+    from irm_amd.mair import SYNTH_RULES as MAIR_RULES
+    arch = import_reference_mairunet()
+    cfg = dict(MAIR_NET_G, img_size=256)
+    net = arch.MaIRUNet(**cfg)
+    sd = synth.synth_state_dict(shapes_of(net), seed=42, rules=MAIR_RULES)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    net.trainig_img_size = -1
+    x = synth_input("mair_in_256x256", (1, 3, 256, 256))
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        y = net(x)[0].numpy()
+    print(f"fullsize c5: reference MaIRUNet forward on 1x3x256x256 took {time.time() - t0:.0f} s; range [{y.min():.3f},{y.max():.3f}]")
+    np.savez_compressed(os.path.join(GOLD, "mair_fullsize_c5.npz"), sub4=y[:, ::4, ::4], mean=y.mean(axis=(1, 2)),
+                        sqmean=(y.astype(np.float64) ** 2).mean(axis=(1, 2)), row77=y[:, 77, :])
+    manifest["mair_fullsize_c5"] = {"input": "synth.uniform(7, 'mair_in_256x256', (1,3,256,256), 0, 1)", "weights_seed": 42,
+                                    "note": "scan op = oracle stand-in (mamba_ssm absent): parity of the scan arithmetic stays unpinned"}
 
 
 def gen_demo(ref, manifest):
@@ -515,7 +631,8 @@ def main():
     manifest = json.load(open(mpath)) if os.path.exists(mpath) else {}
     ref = import_reference()
     steps = {"ops": gen_ops, "restormer": gen_restormer, "convnets": gen_convnets, "tiler": gen_tiler,
-             "deblurgan": gen_deblurgan, "fullsize": gen_fullsize, "demo": gen_demo, "mair": gen_mair}      # mair last: it re-stubs the `mair` package for the reference's arch file
+             "deblurgan": gen_deblurgan, "fpn_inception": gen_fpn_inception, "fullsize": gen_fullsize, "fullsize_c3": gen_fullsize_c3, "demo": gen_demo, "mair": gen_mair,
+             "fullsize_c5": gen_fullsize_c5}      # mair last: it re-stubs the `mair` package for the reference's arch file
     for k, fn in steps.items():
         if args.only in (None, k):
             fn(ref, manifest)

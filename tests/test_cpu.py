@@ -349,3 +349,21 @@ def test_bench_self_launch_command(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_split_range_guard_falls_back_per_layer():
+    """The unscaled fp16 hi/lo split of the streaming GEMMs is used only inside its safe range; outside it the layer
+    keeps the exact f32 weights."""
+    w = torch.randn(64, 48) * 0.1
+    assert _hip.split_is_safe(w) and _hip.split_is_safe(w, torch.ones(48), torch.zeros(48))
+    assert not _hip.split_is_safe(w * 1e6)                                   # hi overflows
+    assert not _hip.split_is_safe(w * 1e-4)                                  # every weight below the fp16 resolution window
+    assert not _hip.split_is_safe(w, torch.full((48,), 6000.0), None)        # LN gain * sqrt(K) leaves fp16
+    assert not _hip.split_is_safe(w * float("nan"))
+    m = restormer.Restormer(dim=16, num_blocks=(1, 1, 1, 1), num_refinement_blocks=1, heads=(1, 1, 1, 1)).load_synthetic(3)
+    with torch.no_grad():
+        m.latent[0].norm1.body.weight.mul_(1e4)                              # a "trained" outlier in ONE layer
+        m.latent[0].ffn.project_out.weight.mul_(1e-5)
+    pk = m._pack()
+    assert "qkv_s" not in pk["latent.0"] and "pout_s" not in pk["latent.0"] and "pin_s" in pk["latent.0"]
+    assert "qkv_s" in pk["encoder_level3.0"] and "pout_s" in pk["encoder_level3.0"]

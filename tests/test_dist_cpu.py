@@ -31,9 +31,9 @@ def _worker(rank, world, port, steps, q):
         inp, tgt = synth.synth_image_pair(i, 32, 48, 3, seed_base=1000, blur=5)
         rows.append((i, tiler_ref.psnr(tgt, inp)))
     elapsed = 0.01 * (rank + 1)
-    tmax, table = parallel.gather_results(elapsed, rows, torch.device("cpu"))
+    tmax, table, failed = parallel.gather_results(elapsed, rows, torch.device("cpu"), failed_ids=[1000 + rank] if rank else [])
     if rank == 0:
-        q.put((tmax, table.tolist()))
+        q.put((tmax, table.tolist(), failed))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,7 +49,8 @@ def test_two_rank_shard_and_gather():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    tmax, table = q.get()
+    tmax, table, failed = q.get()
+    assert failed == [1001]                                         # rank 1's failed image id reaches rank 0
     assert abs(tmax - 0.02) < 1e-9                                  # MAX over ranks
     table = np.array(table)
     assert sorted(table[:, 0].astype(int).tolist()) == list(range(world * steps))   # every image exactly once

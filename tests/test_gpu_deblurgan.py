@@ -128,3 +128,23 @@ def test_deblurgan_tiled_vs_oracle(dev):
     cfg = utils.get_patch_config("deblurring", "motion", "DeblurGANv2 (MobileNet)")
     pred2, _ = utils.get_model_prediction(model, img, dev, **cfg)           # one 100x150 tile padded to 128x160
     assert pred2.shape == img.shape and pred2.dtype == np.uint8
+
+
+@pytest.mark.parametrize("h,w", [(128, 160), (256, 128)])
+def test_fpn_inception_decoder_vs_golden(dev, golden, h, w):
+    """The in-tree part of FPN-Inception (laterals, reflect pads, top-down path, heads, smoothing, tanh/clamp output,
+    fpn_inception.py:65-81, 153-170) on synthetic encoder maps against the reference class run with constant-output
+    encoder stages (gen_golden.py --only fpn_inception).  The timm encoder itself is absent: unpinned."""
+    g = golden("fpn_inception")
+    model = deblurganv2.FPNInceptionDecoder().load_synthetic(42).to(dev).train(True)
+    x = gin(f"fi_in_{h}x{w}", (1, 3, h, w), -1.0, 1.0)
+    chans = (32, 64, 192, 1088, 2080)
+    encs = [gin(f"fi_enc{i}_{h}x{w}", (1, chans[i]) + tuple(int(v) for v in g[f"fi_sizes_{h}x{w}"][i]), -1.0, 1.0).to(dev)
+            for i in range(5)]
+    y = model(x.to(dev), *encs).cpu().numpy()
+    err = np.abs(y - g[f"fi_{h}x{w}"]).max()
+    print(f"fpn_inception decoder {h}x{w}: max-abs vs reference golden {err:.3e}")
+    assert err <= 2e-4
+    # batched tiles stay independent (train-mode norms use per-sample statistics)
+    y2 = model(torch.cat([x, x.flip(-1)]).to(dev), *[torch.cat([e, e.flip(-1)]) for e in encs])[:1].cpu().numpy()
+    assert np.abs(y2 - y).max() <= 1e-5

@@ -46,6 +46,57 @@ def test_fullsize_tile_vs_reference_golden(dev, model, frame, golden):
     assert err <= 1e-3 and m_err <= 1e-5 and s_err <= 1e-5
 
 
+def _check_sub(y, g, sub, row):
+    err = max(np.abs(y[:, ::sub, ::sub] - g[f"sub{sub}"]).max(), np.abs(y[:, row, :] - g[f"row{row}"]).max())
+    m_err = np.abs(y.mean(axis=(1, 2)) - g["mean"]).max()
+    s_err = np.abs((y.astype(np.float64) ** 2).mean(axis=(1, 2)) - g["sqmean"]).max()
+    return err, m_err, s_err
+
+
+def test_fullsize_c3_biasfree_tile_vs_reference_golden(dev, golden):
+    """BASELINE configs[2]: Restormer colour blind-denoise (BiasFree LayerNorm) on one full 256x256 tile of the 512x512
+    frame, against the imported reference's output on the same (noisy) tile (gen_golden.py --only fullsize_c3)."""
+    g = golden("restormer_fullsize_c3")
+    model = restormer.Restormer(LayerNorm_type="BiasFree").load_synthetic(42).eval().to(dev)
+    x = torch.from_numpy(g["x"])[None].to(dev)
+    y = model(x)[0].cpu().numpy()
+    err, m_err, s_err = _check_sub(y, g, 4, 77)
+    print(f"c3 256x256 BiasFree tile vs reference golden: max-abs {err:.3e}, channel mean {m_err:.2e}, mean square {s_err:.2e}")
+    assert err <= 1e-3 and m_err <= 1e-5 and s_err <= 1e-5
+
+
+def test_fullsize_c3_nine_tiles_properties(dev):
+    """configs[2] whole frame (512x512, 9 tiles of 256 with overlap): run-to-run bit identity and batched == per-tile
+    after requantisation."""
+    model = restormer.Restormer(LayerNorm_type="BiasFree").load_synthetic(42).eval().to(dev)
+    inp, _ = synth.synth_image_pair(3, 512, 512, 3, seed_base=1000, blur=0)
+    cfg = utils.get_patch_config("denoising", "gaussian", "Restormer")          # 256 / 48
+    img = torch.from_numpy(inp).to(dev)
+    a, _ = utils.tiled_forward_device(model, img, cfg["patch_size"], cfg["patch_overlap"], pad8=True, max_batch=9)
+    b, _ = utils.tiled_forward_device(model, img, cfg["patch_size"], cfg["patch_overlap"], pad8=True, max_batch=9)
+    assert torch.equal(a, b)
+    c, _ = utils.tiled_forward_device(model, img, cfg["patch_size"], cfg["patch_overlap"], pad8=True, max_batch=1)
+    diff = (a.int() - c.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3
+
+
+def test_fullsize_c5_mairunet_vs_reference_golden(dev, golden):
+    """BASELINE configs[4]: MaIRUNet on a full 256x256 crop (scan length 65 536 at level 1, the product scan_plan
+    chunking) against the imported reference module's output (scan op = oracle stand-in: that arithmetic stays
+    unpinned)."""
+    from irm_amd.mair import mairunet_arch
+    g = golden("mair_fullsize_c5")
+    model = mairunet_arch.MaIRUNet(inp_channels=3, out_channels=3, dim=48, num_blocks=[4, 6, 6, 8], num_refinement_blocks=4,
+                                   ssm_ratio=2.0, flp_ratio=4.0, mlp_ratio=1.5, bias=False, dual_pixel_task=False,
+                                   img_size=256, scan_len=4, batch_size=1, dynamic_ids=False)
+    model = model.load_synthetic(42).eval().to(dev)
+    x = synth.uniform(7, "mair_in_256x256", (1, 3, 256, 256), 0.0, 1.0).to(dev)
+    y = model(x)[0].cpu().numpy()
+    err, m_err, s_err = _check_sub(y, g, 4, 77)
+    print(f"c5 MaIRUNet 256x256 vs reference golden: max-abs {err:.3e}, channel mean {m_err:.2e}, mean square {s_err:.2e}")
+    assert err <= 1e-3 and m_err <= 1e-4 and s_err <= 1e-4
+
+
 def test_fullsize_batch_independence_and_determinism(dev, model, frame):
     """Tile 0 alone, tile 0 inside the batch of 6, and a repeated run."""
     img = torch.from_numpy(frame[0]).to(dev)

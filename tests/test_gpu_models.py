@@ -100,6 +100,31 @@ def test_transformer_block_vs_golden(dev, golden, c, heads, h, w, ln):
     assert err <= 2e-4
 
 
+@pytest.mark.parametrize("c,heads,h,w,ln", TB_CASES)
+def test_transformer_block_product_path_vs_golden(dev, golden, c, heads, h, w, ln):
+    """The same reference goldens through the path users and bench.py run: weights packed by Restormer._pack()
+    (fp16 hi/lo splits, range guard, fused branch kernels for C <= 96) and the stage driver _run_stage."""
+    import torch.nn as nn
+    tag = f"c{c}_h{heads}_{h}x{w}_{ln}"
+    host = restormer.Restormer(LayerNorm_type=ln)
+    blk = restormer.restormer.TransformerBlock(c, heads, 2.66, False, ln)
+    shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    blk.load_state_dict(synth.synth_state_dict(shapes, seed=11, rules=restormer.restormer.SYNTH_RULES))
+    host.encoder_level1 = nn.Sequential(blk)
+    host = host.to(dev)
+    pk = host._pack()
+    wt = pk["encoder_level1.0"]
+    assert host._split and "qkv_s" in wt and "pin_s" in wt and "pout_s" in wt
+    assert ("gdfn_f" in wt) == (c <= 96)
+    x = gin("tb_in_" + tag, (2, c, h, w), -1.0, 1.0).to(dev)
+    y = x.clone()
+    host._run_stage("encoder_level1", pk, y)
+    g = golden("restormer_ops")
+    err = np.abs(y.cpu().numpy() - g["tb_" + tag + "_out"]).max()
+    print(f"block {tag} (product path): max-abs vs reference golden {err:.3e}")
+    assert err <= 2e-4
+
+
 @pytest.mark.parametrize("c,h,w", [(48, 16, 24), (96, 8, 16)])
 def test_resample_vs_golden(dev, golden, c, h, w):
     g = golden("restormer_ops")
