@@ -35,6 +35,7 @@ SIGNATURES = {
     "irm_mdta_finalize_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "irm_mdta_finalize_f16x3_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "irm_conv3x3_f32": [_P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "irm_conv3x3_f16x3_f32": [_P, _F, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "irm_tile_extract": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "irm_chan_stats_f32": [_P, _L, _P, _I, _I, _I, _F, _P],
     "irm_chan_stats_ws_f32": [_P, _L, _P, _P, _L, _I, _I, _I, _F, _P],
@@ -152,6 +153,43 @@ def pack_conv3x3_weight(w: torch.Tensor) -> torch.Tensor:
     wpad = torch.zeros(9, mt * 16, ks * 4, dtype=torch.float32, device=w.device)
     wpad[:, :co, :ci] = w.reshape(co, ci, 9).permute(2, 0, 1)
     return wpad.view(9, mt, 16, ks, 4).permute(0, 1, 3, 4, 2).contiguous().view(-1)
+
+
+def pack_conv3x3_weight_split(w: torch.Tensor):
+    """W [Co][Ci][3][3] -> operands of irm_conv3x3_f16x3_f32: (wp, inv_scale) with
+    wp[mtile][stage][tap][hi|lo][lane = 16 g + m][8 halves j] = part(W[16 mtile + m][32 stage + 8 g + j][tap] * s),
+    s a power of two with max|W| s in [2^13, 2^14) (lo parts stay normal fp16 numbers), inv_scale = 16 / s (the kernel
+    scales the activations by 2^-4 before their split)."""
+    w = w.detach().float().cpu()
+    co, ci = w.shape[:2]
+    mt, st = (co + 15) // 16, (ci + 31) // 32
+    s = _pow2_scale(w)
+    wpad = torch.zeros(mt * 16, st * 32, 9, dtype=torch.float32)
+    wpad[:co, :ci] = w.reshape(co, ci, 9) * s
+    hi, lo = _split_h(wpad)
+
+    def arr(t):       # [mt][16 m][st][4 g][8 j][9 tap] -> [mt][st][tap][g][m][j]
+        return t.view(mt, 16, st, 4, 8, 9).permute(0, 2, 5, 3, 1, 4)
+    packed = torch.stack([arr(hi), arr(lo)], dim=3).contiguous()          # [mt][st][tap][2][g][m][8]
+    return packed.view(-1).view(torch.float32), 16.0 / s
+
+
+class ConvWeight:
+    """A 3x3 conv weight packed for both kernels: `exact` (irm_conv3x3_f32) always, `split` + `inv_scale`
+    (irm_conv3x3_f16x3_f32) unless IRM_GEMM_EXACT is set; ops.conv3x3 picks the emulated kernel where its alignment
+    requirements hold."""
+    __slots__ = ("exact", "split", "inv_scale")
+
+    def __init__(self, exact, split=None, inv_scale=1.0):
+        self.exact, self.split, self.inv_scale = exact, split, inv_scale
+
+
+def pack_conv3x3(w: torch.Tensor) -> ConvWeight:
+    exact = pack_conv3x3_weight(w)
+    if os.environ.get("IRM_GEMM_EXACT"):
+        return ConvWeight(exact)
+    split, inv = pack_conv3x3_weight_split(w)
+    return ConvWeight(exact, split.to(w.device), inv)
 
 
 def pack_dw_table(w9: torch.Tensor, bias, K: int, gate: bool) -> torch.Tensor:

@@ -66,7 +66,7 @@ class FPNInceptionDecoder(nn.Module):
 
     def _build(self):
         f32 = lambda t: None if t is None else t.detach().float().contiguous()      # noqa: E731
-        c3 = lambda conv: (_hip.pack_conv3x3_weight(conv.weight), f32(conv.bias))    # noqa: E731
+        c3 = lambda conv: (_hip.pack_conv3x3(conv.weight), f32(conv.bias))    # noqa: E731
         pk = {f"lateral{i}": _hip.pack_gemm_weight(getattr(self.fpn, f"lateral{i}").weight) for i in range(5)}
         for n in ("td1", "td2", "td3"):
             pk[n] = c3(getattr(self.fpn, n)[0])

@@ -107,7 +107,7 @@ class FPNMobileNet(nn.Module):
     def _build(self):
         f32 = lambda t: None if t is None else t.detach().float().contiguous()      # noqa: E731
         g1 = lambda conv: _hip.pack_gemm_weight(conv.weight)                         # noqa: E731
-        c3 = lambda conv: (_hip.pack_conv3x3_weight(conv.weight), f32(conv.bias))    # noqa: E731
+        c3 = lambda conv: (_hip.pack_conv3x3(conv.weight), f32(conv.bias))    # noqa: E731
         pk = {"stem_w": f32(self.fpn.features[0][0].weight), "stem_bn": (f32(self.fpn.features[0][1].weight),
                                                                           f32(self.fpn.features[0][1].bias))}
         blocks = []

@@ -34,7 +34,7 @@ class DnCNN(nn.Module):
         return [m for m in self.model if isinstance(m, nn.Conv2d)]
 
     def _build(self):
-        return [(_hip.pack_conv3x3_weight(m.weight), m.bias.detach().float().contiguous(),
+        return [(_hip.pack_conv3x3(m.weight), m.bias.detach().float().contiguous(),
                  m.in_channels, m.out_channels) for m in self._convs()]
 
     def load_synthetic(self, seed=42):

@@ -70,7 +70,7 @@ class MaIR(MambaHost):
         if self._packed is not None and self._packed_key == key:
             return self._packed
         f32 = lambda t: None if t is None else t.detach().float().contiguous()       # noqa: E731
-        c3 = lambda conv: (_hip.pack_conv3x3_weight(conv.weight), f32(conv.bias))     # noqa: E731
+        c3 = lambda conv: (_hip.pack_conv3x3(conv.weight), f32(conv.bias))     # noqa: E731
         dev = self.conv_first.weight.device
         E = self.embed_dim
         pk = {name: pack_block(m) for name, m in self.named_modules() if isinstance(m, VSSBlock)}

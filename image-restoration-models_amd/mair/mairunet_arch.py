@@ -274,9 +274,9 @@ class MaIRUNet(MambaHost):
 
         pk = {name: pack_block(m) for name, m in self.named_modules() if isinstance(m, VSSBlock)}
         for name in ("down1_2", "down2_3", "down3_4", "up4_3", "up3_2", "up2_1"):
-            pk[name] = _hip.pack_conv3x3_weight(getattr(self, name).body[0].weight)
-        pk["patch_embed"] = _hip.pack_conv3x3_weight(self.patch_embed.proj.weight)
-        pk["output"] = _hip.pack_conv3x3_weight(self.output.weight)
+            pk[name] = _hip.pack_conv3x3(getattr(self, name).body[0].weight)
+        pk["patch_embed"] = _hip.pack_conv3x3(self.patch_embed.proj.weight)
+        pk["output"] = _hip.pack_conv3x3(self.output.weight)
         pk["output_b"] = f32(self.output.bias)
         for name in ("reduce_chan_level3", "reduce_chan_level2") + (("skip_conv",) if self.dual_pixel_task else ()):
             pk[name] = _hip.pack_gemm_weight(getattr(self, name).weight)

@@ -254,11 +254,32 @@ def mfold_numel(C: int) -> int:
 
 def conv3x3(wp, x, y, ci: int, co: int, *, bias=None, relu1=False, res=None, res_mode=0, relu2=False,
             store_mode=0, ct: int | None = None, ygroups: int | None = None):
-    """Dense 3x3 conv with fused epilogue; store_mode 1 = PixelUnshuffle(2), 2 = PixelShuffle(2)."""
+    """Dense 3x3 conv with fused epilogue; store_mode 1 = PixelUnshuffle(2), 2 = PixelShuffle(2).
+    wp: _hip.pack_conv3x3_weight(w) (exact f32 MFMA) or the pair _hip.pack_conv3x3_weight_split(w) (fp32 emulated on
+    the fp16 matrix cores, irm_conv3x3_f16x3_f32; needs W % 4 == 0 and 16-byte aligned rows)."""
     _chk(x, "x"), _chk(y, "y")
     B, _, H, W = x.shape
     mt = (co + 15) // 16
     blocks = -(-W // 32) * -(-H // 8) * B
+    nbytes = 4.0 * B * H * W * (ci + co + (co if res is not None else 0))
+    if isinstance(wp, _hip.ConvWeight):
+        aligned = (W % 4 == 0 and _bs(x) % 4 == 0 and _bs(y) % 4 == 0 and _bs(res) % 4 == 0 and x.data_ptr() % 16 == 0
+                   and y.data_ptr() % 16 == 0 and (res is None or res.data_ptr() % 16 == 0))
+        wp = (wp.split, wp.inv_scale) if (wp.split is not None and aligned) else wp.exact
+    if isinstance(wp, tuple):
+        wps, inv_scale = wp
+        if ct is None:
+            ct = 4 if mt % 4 == 0 or mt > 9 else 3 if mt % 3 == 0 or mt > 4 else min(mt, 4)
+            while ct > 1 and blocks * -(-mt // ct) < 256:       # small images: more passes, more workgroups
+                ct -= 1
+        if ygroups is None:
+            nchunks = -(-mt // ct)
+            ygroups = max(1, min(nchunks, -(-512 // blocks)))
+        _launch("conv3x3_f16x3", 18.0 * B * ci * co * H * W, nbytes, "irm_conv3x3_f16x3_f32", _hip.ptr(wps), float(inv_scale),
+                _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), B, ci, co, H, W,
+                int(relu1), int(res_mode), int(relu2), int(store_mode), ct, ygroups,
+                tag=f"ci{ci} co{co} {H}x{W} B{B} ct{ct} yg{ygroups} st{store_mode}")
+        return
     if ct is None:
         ct = _hip.choose_ct(mt, (6, 4, 3, 2, 1))
         # small images (FPN levels, level-4 tiles): fewer output tiles per workgroup so that the chip is filled
@@ -269,7 +290,6 @@ def conv3x3(wp, x, y, ci: int, co: int, *, bias=None, relu1=False, res=None, res
     if ygroups is None:
         nchunks = -(-mt // ct)
         ygroups = max(1, min(nchunks, -(-target_blocks() // blocks)))
-    nbytes = 4.0 * B * H * W * (ci + co + (co if res is not None else 0))
     _launch("conv3x3", 18.0 * B * ci * co * H * W, nbytes, "irm_conv3x3_f32", _hip.ptr(wp), _hip.ptr(x), _bs(x),
             _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), B, ci, co, H, W, int(relu1), int(res_mode),
             int(relu2), int(store_mode), ct, ygroups, tag=f"ci{ci} co{co} {H}x{W} B{B} ct{ct} yg{ygroups} st{store_mode}")

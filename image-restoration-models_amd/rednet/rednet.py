@@ -24,9 +24,9 @@ class REDNet(nn.Module):
         self._cache = PackedCache(self, self._build)
 
     def _build(self):
-        enc = [(_hip.pack_conv3x3_weight(m.weight), m.bias.detach().float().contiguous(), m.in_channels, m.out_channels)
+        enc = [(_hip.pack_conv3x3(m.weight), m.bias.detach().float().contiguous(), m.in_channels, m.out_channels)
                for m in (getattr(self, f"conv{i}") for i in range(1, 16))]
-        dec = [(_hip.pack_conv3x3_weight(_hip.deconv_as_conv_weight(m.weight)), m.bias.detach().float().contiguous(),
+        dec = [(_hip.pack_conv3x3(_hip.deconv_as_conv_weight(m.weight)), m.bias.detach().float().contiguous(),
                 m.in_channels, m.out_channels) for m in (getattr(self, f"deconv{i}") for i in range(1, 16))]
         return enc, dec
 

@@ -211,10 +211,10 @@ class Restormer(nn.Module):
                         v_dwp=_hip.pack_dw_table(dw[2 * c:], None if dwb is None else dwb[2 * c:], c, False),
                         ffn_dwp=_hip.pack_dw_table(ff.dwconv.weight, ff.dwconv.bias, ff.hidden, True))
         for name in ("down1_2", "down2_3", "down3_4", "up4_3", "up3_2", "up2_1"):
-            pk[name] = _hip.pack_conv3x3_weight(getattr(self, name).body[0].weight)
-        pk["patch_embed"] = _hip.pack_conv3x3_weight(self.patch_embed.proj.weight)
+            pk[name] = _hip.pack_conv3x3(getattr(self, name).body[0].weight)
+        pk["patch_embed"] = _hip.pack_conv3x3(self.patch_embed.proj.weight)
         pk["patch_embed_b"] = f32(self.patch_embed.proj.bias)
-        pk["output"] = _hip.pack_conv3x3_weight(self.output.weight)
+        pk["output"] = _hip.pack_conv3x3(self.output.weight)
         pk["output_b"] = f32(self.output.bias)
         for name in ("reduce_chan_level3", "reduce_chan_level2") + (("skip_conv",) if self.dual_pixel_task else ()):
             pk[name] = _hip.pack_gemm_weight(getattr(self, name).weight)

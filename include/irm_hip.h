@@ -197,6 +197,16 @@ int irm_conv3x3_f32(const float* wp, const float* x, long x_bs, float* y, long y
                     const float* bias, int B, int Ci, int Co, int H, int W, int relu1, int res_mode, int relu2,
                     int store_mode, int ct, int ygroups, irm_stream_t stream);
 
+/* irm_conv3x3_f32 as an fp32 emulation on the fp16 matrix cores (three v_mfma_f32_16x16x32_f16 per product: lo*hi,
+ * hi*lo, hi*hi, fp32 accumulate; the staged halo tile is split ONCE per 32-channel stage into a channel-minor fp16 hi/lo
+ * image in LDS and reused by 9 taps x all output tiles).  Same epilogue and store modes; needs W % 4 == 0 and 16-byte
+ * aligned rows.  wp_split [ceil(Co/16)][ceil(Ci/32)][9 taps][hi|lo][64 lanes][8 halves]: lane = 16 g + m, half j ->
+ * W[16 mtile + m][32 stage + 8 g + j][tap] * s, split into fp16 hi + lo; s a power of two with max|W| s in [2^13, 2^14);
+ * inv_scale = 16 / s (activations are scaled by 2^-4 before their split: |x| < 1e6).  ct in {1, 2, 3, 4}. */
+int irm_conv3x3_f16x3_f32(const float* wp_split, float inv_scale, const float* x, long x_bs, float* y, long y_bs,
+                          const float* res, long r_bs, const float* bias, int B, int Ci, int Co, int H, int W, int relu1,
+                          int res_mode, int relu2, int store_mode, int ct, int ygroups, irm_stream_t stream);
+
 /* Tile extraction for the tiled-patch loop (src/utils.py:379-417):
  * img [H][W][C] uint8 (is_u16=0) or uint16 -> tiles [T][C][ph][pw] float32 =
  * img/255 (or /65535), + optional float64 noise field [th][tw][C] then clip

@@ -375,3 +375,56 @@ def test_rejects_bad_arguments(dev):
         ops.conv3x3(torch.zeros(9 * 64, device=dev), x, torch.empty(1, 16, 1, 2, device=dev), 4, 4, store_mode=1)
     with pytest.raises(ValueError):
         ops.ln_stats(torch.zeros(1, 4, 4, 4), torch.zeros(32))          # CPU tensor
+
+
+CONV_F16_CASES = [
+    # ci, co, H, W, B, bias, relu1, res_mode, relu2, store_mode, ct
+    (64, 64, 16, 32, 2, True, True, 0, False, 0, None),
+    (3, 48, 24, 40, 1, False, False, 0, False, 0, None),       # patch embed: one padded stage
+    (48, 24, 16, 32, 2, False, False, 0, False, 1, None),      # down: PixelUnshuffle
+    (96, 192, 8, 32, 1, False, False, 0, False, 2, 3),         # up: PixelShuffle
+    (96, 3, 16, 36, 1, True, False, 1, False, 0, None),        # output conv + global residual, partial tile
+    (1, 64, 12, 20, 1, True, True, 0, False, 0, None),         # DnCNN first layer (gray)
+    (64, 1, 12, 20, 1, True, False, 2, False, 0, None),        # DnCNN last layer: x - conv
+    (128, 128, 8, 8, 2, True, False, 1, True, 0, 4),           # REDNet-style: conv + skip + relu
+    (70, 50, 20, 44, 1, True, False, 0, False, 0, 2),          # ragged channel counts
+]
+
+
+@pytest.mark.parametrize("ci,co,H,W,B,bias,relu1,res_mode,relu2,store_mode,ct", CONV_F16_CASES)
+def test_conv3x3_f16x3(dev, ci, co, H, W, B, bias, relu1, res_mode, relu2, store_mode, ct):
+    """irm_conv3x3_f16x3_f32 (fp32 emulated on the fp16 matrix cores) vs float64, next to the exact-f32 kernel on the
+    same inputs: its error must not exceed 2x the exact kernel's (+ fp32 rounding of the output)."""
+    tag = f"cf{ci}_{co}_{H}_{W}_{store_mode}"
+    w = rnd(tag + "w", (co, ci, 3, 3), -0.2, 0.2)
+    x = rnd(tag + "x", (B, ci, H, W), -1.5, 2.0)
+    bv = rnd(tag + "b", (co,)) if bias else None
+    oc, oh, ow = (co, H, W) if store_mode == 0 else (co * 4, H // 2, W // 2) if store_mode == 1 else (co // 4, 2 * H, 2 * W)
+    r = rnd(tag + "r", (B, oc, oh, ow)) if res_mode else None
+    ref = F.conv2d(x.double(), w.double(), None if bv is None else bv.double(), padding=1)
+    if relu1:
+        ref = F.relu(ref)
+    if res_mode == 1:
+        ref = ref + r.double()
+    elif res_mode == 2:
+        ref = r.double() - ref
+    if relu2:
+        ref = F.relu(ref)
+    if store_mode == 1:
+        ref = F.pixel_unshuffle(ref, 2)
+    elif store_mode == 2:
+        ref = F.pixel_shuffle(ref, 2)
+    xd = x.to(dev)
+    kw = dict(bias=None if bv is None else bv.to(dev), relu1=relu1, res=None if r is None else r.to(dev), res_mode=res_mode,
+              relu2=relu2, store_mode=store_mode)
+    y16 = torch.full((B, oc + 1, oh, ow), 7.0, device=dev)
+    wps, inv = _hip.pack_conv3x3_weight_split(w)
+    ops.conv3x3((wps.to(dev), inv), xd, y16[:, :oc], ci, co, ct=ct, **kw)
+    y32 = torch.empty(B, oc, oh, ow, device=dev)
+    ops.conv3x3(_hip.pack_conv3x3_weight(w).to(dev), xd, y32, ci, co, **kw)
+    e16 = float((y16[:, :oc].cpu().double() - ref).abs().max())
+    e32 = float((y32.cpu().double() - ref).abs().max())
+    scale = max(1.0, float(ref.abs().max()))
+    print(f"conv3x3 f16x3 {tag}: {e16:.3e} (exact f32 kernel {e32:.3e})")
+    assert e16 <= TOL * scale and e16 <= 2.0 * e32 + 4e-7 * scale
+    assert torch.all(y16[:, oc] == 7.0)
