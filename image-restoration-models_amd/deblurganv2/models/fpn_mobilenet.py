@@ -95,6 +95,7 @@ class FPNMobileNet(nn.Module):
         self.final = nn.Conv2d(num_filters // 2, output_ch, 3, padding=1)
         self._cache = PackedCache(self, self._build)
         self.max_tiles_per_batch = 2
+        self.hip_graph = True      # the tiler replays the per-batch forward from a HIP graph (utils.graphed_forward)
 
     # ------------------------------------------------------------------ weights
     def load_synthetic(self, seed=42):

@@ -28,6 +28,7 @@ class DnCNN(nn.Module):
                 layers.append(nn.ReLU(inplace=True))
         self.model = nn.Sequential(*layers)      # parameter holder: never called
         self._cache = PackedCache(self, self._build)
+        self.hip_graph = True      # the tiler replays the per-batch forward from a HIP graph (utils.graphed_forward)
         self._ws = {}
 
     def _convs(self):

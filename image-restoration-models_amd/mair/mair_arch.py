@@ -58,6 +58,7 @@ class MaIR(MambaHost):
         self.conv_last = nn.Conv2d(embed_dim, in_chans, 3, 1, 1)
         self._init_host()
         self.max_tiles_per_batch = 8
+        self.hip_graph = True      # the tiler replays the per-batch forward from a HIP graph (utils.graphed_forward)
 
     def load_synthetic(self, seed=42):
         from .. import synth

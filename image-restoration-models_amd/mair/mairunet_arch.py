@@ -256,6 +256,7 @@ class MaIRUNet(MambaHost):
         self.output = nn.Conv2d(d2, out_channels, 3, padding=1, bias=bias)
         self._init_host()
         self.max_tiles_per_batch = 4
+        self.hip_graph = True      # the tiler replays the per-batch forward from a HIP graph (utils.graphed_forward)
 
     # ------------------------------------------------------------------ weights
     def load_synthetic(self, seed=42):

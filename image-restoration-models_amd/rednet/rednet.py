@@ -22,6 +22,7 @@ class REDNet(nn.Module):
             setattr(self, f"deconv{i}", nn.ConvTranspose2d(num_features, num_channels if i == 15 else num_features,
                                                            3, padding=1))
         self._cache = PackedCache(self, self._build)
+        self.hip_graph = True      # the tiler replays the per-batch forward from a HIP graph (utils.graphed_forward)
 
     def _build(self):
         enc = [(_hip.pack_conv3x3(m.weight), m.bias.detach().float().contiguous(), m.in_channels, m.out_channels)

@@ -142,6 +142,7 @@ class Restormer(nn.Module):
         self._ws_by_stream = {}
         #: tiles of one image processed per forward by the device tiler (utils.tiled_forward_device)
         self.max_tiles_per_batch = 9
+        self.hip_graph = True      # the tiler replays the per-batch forward from a HIP graph (utils.graphed_forward)
 
     # ------------------------------------------------------------------ weights
     def load_synthetic(self, seed=42):

@@ -213,6 +213,45 @@ def _window_on(device, ps: int) -> torch.Tensor:
     return _WINDOW_CACHE[key]
 
 
+#: (model id, input shape, device, stream, weights version) -> (graph, static input, static output)
+_GRAPHS: dict = {}
+
+
+def _weights_version(model: Module) -> int:
+    return sum(p._version for p in model.parameters())
+
+
+def graphed_forward(model: Module, x: torch.Tensor) -> torch.Tensor:
+    """model(x) replayed from a HIP graph where that pays: the conv stacks and MaIR at small images are bound by
+    the host's launch rate (hundreds of kernels of 10-60 us per image), not by the GPU.
+
+    Opt-in per model (`model.hip_graph = True`, the default of the built-in model classes); off while a KernelTimer
+    is installed (per-launch events need eager launches) and with IRM_NO_GRAPH=1.  The first call for a (model, input
+    shape, stream, weights version) runs eagerly once (weight packing, workspace allocation, LDS attributes), then
+    captures the forward on torch's capture stream - every kernel of libirm_hip.so is enqueued on torch's current
+    stream and allocates nothing, so the capture holds plain kernel nodes; later calls copy the input into the
+    graph's static buffer and replay.  The returned tensor is the graph's static output: consume it (on the same
+    stream) before the next call, as the tiler does."""
+    if (ops.TIMER is not None or not getattr(model, "hip_graph", False) or os.environ.get("IRM_NO_GRAPH")
+            or not x.is_cuda or torch.cuda.is_current_stream_capturing()):
+        return model(x)
+    key = (id(model), tuple(x.shape), x.device.index, torch.cuda.current_stream().cuda_stream, _weights_version(model))
+    ent = _GRAPHS.get(key)
+    if ent is None:
+        for k in [k for k in _GRAPHS if k[0] == id(model) and (k[4] != key[4] or len(_GRAPHS) > 16)]:
+            del _GRAPHS[k]                           # stale weights / bounded cache
+        model(x)                                     # eager warm-up
+        static_in = x.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_out = model(static_in)
+        ent = _GRAPHS[key] = (g, static_in, static_out)
+    g, static_in, static_out = ent
+    static_in.copy_(x)
+    g.replay()
+    return static_out
+
+
 def tiled_forward_device(model: Module, img_dev: torch.Tensor, patch_size, patch_overlap, pad8: bool,
                          noise_sigma=None, target_dev: torch.Tensor | None = None, max_batch: int = 8,
                          keep_tiles: list | None = None, hooks: str | None = None):
@@ -271,7 +310,7 @@ def tiled_forward_device(model: Module, img_dev: torch.Tensor, patch_size, patch
             st = _side_stream(dev, gi)
             st.wait_event(ready)
             with torch.cuda.stream(st):
-                o = model(tiles[i:i + per])
+                o = model(tiles[i:i + per])              # (side streams: eager)
                 outs.append((i, o))
                 ev = torch.cuda.Event()
                 ev.record(st)
@@ -284,7 +323,7 @@ def tiled_forward_device(model: Module, img_dev: torch.Tensor, patch_size, patch
             o.record_stream(main)
     else:
         for i in range(0, T, max_batch):
-            o = model(tiles[i:i + max_batch])
+            o = graphed_forward(model, tiles[i:i + max_batch]) if callable(getattr(model, "forward", None)) else model(tiles[i:i + max_batch])
             if pred is None:
                 pred = o if o.shape[0] == T else torch.empty(T, *o.shape[1:], dtype=torch.float32, device=dev)
             if pred is not o:

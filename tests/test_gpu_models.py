@@ -278,3 +278,39 @@ def test_get_model_prediction_surface(dev):
     assert pred.dtype == np.uint8 and pred.shape == img.shape and ms > 0
     with pytest.raises(_hip.HipLibraryError):
         model(torch.zeros(1, 3, 64, 64))            # CPU input: no silent fallback
+
+
+@pytest.mark.parametrize("family", ["dncnn", "rednet", "restormer", "mair"])
+def test_graph_replay_equals_eager(dev, family, monkeypatch):
+    """utils.graphed_forward: the HIP-graph replay of the per-batch forward gives the same bytes as eager launches,
+    also on the second and third image (static buffers reused) and after the weights changed (re-capture)."""
+    if family == "dncnn":
+        model, c, cfg = dncnn.DnCNN(1, 1, 64, 17, "R").load_synthetic(1).eval().to(dev), 1, dict(ps=64, ov=16, pad8=False)
+    elif family == "rednet":
+        model, c, cfg = rednet.REDNet().load_synthetic(1).eval().to(dev), 1, dict(ps=64, ov=16, pad8=False)
+    elif family == "restormer":
+        model, c, cfg = restormer.Restormer(LayerNorm_type="BiasFree").load_synthetic(1).eval().to(dev), 3, dict(ps=64, ov=16, pad8=True)
+    else:
+        from irm_amd import mair
+        model = mair.MaIRUNet(dim=48, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1, ssm_ratio=2.0, flp_ratio=4.0,
+                              mlp_ratio=1.5, scan_len=4).load_synthetic(1).eval().to(dev)
+        c, cfg = 3, dict(ps=64, ov=16, pad8=True)
+    assert model.hip_graph
+    imgs = [torch.from_numpy(synth.synth_image_pair(i, 96, 112, c, seed_base=50, blur=3)[0]).to(dev) for i in range(3)]
+
+    def run(i):
+        return utils.tiled_forward_device(model, imgs[i], cfg["ps"], cfg["ov"], pad8=cfg["pad8"], max_batch=2)[0].clone()
+    monkeypatch.setenv("IRM_NO_GRAPH", "1")
+    eager = [run(i) for i in range(3)]
+    monkeypatch.delenv("IRM_NO_GRAPH")
+    utils._GRAPHS.clear()
+    graphed = [run(i) for i in range(3)] + [run(0)]
+    assert len(utils._GRAPHS) >= 1
+    for a, b in zip(eager + [eager[0]], graphed):
+        assert torch.equal(a, b)
+    # new weights -> the old graph must not be replayed
+    model.load_synthetic(2)
+    monkeypatch.setenv("IRM_NO_GRAPH", "1")
+    e2 = run(1)
+    monkeypatch.delenv("IRM_NO_GRAPH")
+    assert torch.equal(run(1), e2) and not torch.equal(e2, eager[1])
