@@ -324,11 +324,16 @@ def deconv_as_conv_weight(w: torch.Tensor) -> torch.Tensor:
     return w.detach().transpose(0, 1).flip(-1, -2).contiguous()
 
 
-def choose_ct(mtiles: int, options=(9, 8, 6, 4, 3)) -> int:
-    """Output-channel tiles per pass: least padding, then the largest tile."""
+def choose_ct(mtiles: int, options=(9, 8, 6, 4, 3), blocks: int = 1 << 30, want: int = 256) -> int:
+    """Output-channel tiles per pass: least padding, then the largest tile.  `blocks` = pixel tiles x images of the
+    launch: when even one workgroup per (pixel tile, pass) would leave most of the 256 CUs idle (single small images:
+    MaIRUNet's 32x32 / 64x64 levels), narrower passes that reach `want` workgroups win over padding."""
     best = None
     for ct in options:
-        waste = -(-mtiles // ct) * ct - mtiles
-        if best is None or waste < best[0]:
-            best = (waste, ct)
+        chunks = -(-mtiles // ct)
+        waste = chunks * ct - mtiles
+        short = max(0, want - blocks * chunks)
+        key = (short, waste)
+        if best is None or key < best[0]:
+            best = (key, ct)
     return best[1]

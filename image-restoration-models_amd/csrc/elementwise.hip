@@ -5,42 +5,54 @@
 // ---------------------------------------------------------------------------
 // LayerNorm statistics over the channel axis (restormer.py:25-70): per pixel
 // mean and rstd = 1/sqrt(biased var + eps).  One thread owns 4 consecutive
-// pixels (16-byte loads, a wave reads 1 KiB per channel row) and runs Welford
-// over the C rows, so x is read exactly once.
-template <bool VEC>
+// pixels (16-byte loads) and runs Welford over its share of the C rows, so x is
+// read exactly once.  A workgroup = PQ pixel quads x G = 256 / PQ channel groups
+// (group g takes channels g, g + G, ...; the partials are merged in group order by
+// Chan's formula).  PQ follows the plane size only (64 / 16 / 4 quads for large /
+// medium / small planes - small planes need the channel axis for parallelism: a
+// 32x32 level has 4 workgroups of 96-deep dependent loops otherwise), never the
+// batch size: an image's statistics do not depend on what it is batched with.
+template <bool VEC, int PQ>
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, long x_bs,
                                                        float* __restrict__ stats, int C, int N, float eps) {
-    // 64 pixel quads x 4 channel groups per workgroup: wave w runs Welford over channels w, w+4, ...
-    // (every load is a contiguous 1 KiB row segment); the four partials are merged in wave order.
-    __shared__ float4 pm[4][64], pq[4][64];
+    constexpr int G = 256 / PQ;
+    __shared__ float4 pm[G][PQ], pq[G][PQ];
     const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int n = (blockIdx.x * 64 + lane) * 4;
+    const int q = threadIdx.x % PQ, g = threadIdx.x / PQ;
+    const int n = (blockIdx.x * PQ + q) * 4;
     const float* p = x + (long)b * x_bs;
     float4 mean = make_float4(0.f, 0.f, 0.f, 0.f), m2 = mean;
     int cnt = 0;
+    auto push = [&](const float4& v) {
+        const float rc = 1.0f / (float)(++cnt);
+        float d;
+        d = v.x - mean.x; mean.x += d * rc; m2.x += d * (v.x - mean.x);
+        d = v.y - mean.y; mean.y += d * rc; m2.y += d * (v.y - mean.y);
+        d = v.z - mean.z; mean.z += d * rc; m2.z += d * (v.z - mean.z);
+        d = v.w - mean.w; mean.w += d * rc; m2.w += d * (v.w - mean.w);
+    };
     if (n < N) {
-        for (int c = w; c < C; c += 4) {
-            const float4 v = irm_ld4<VEC>(p + (long)c * N, n, N);
-            const float rc = 1.0f / (float)(++cnt);
-            float d;
-            d = v.x - mean.x; mean.x += d * rc; m2.x += d * (v.x - mean.x);
-            d = v.y - mean.y; mean.y += d * rc; m2.y += d * (v.y - mean.y);
-            d = v.z - mean.z; mean.z += d * rc; m2.z += d * (v.z - mean.z);
-            d = v.w - mean.w; mean.w += d * rc; m2.w += d * (v.w - mean.w);
+        int c = g;
+        for (; c + 3 * G < C; c += 4 * G) {                  // four rows in flight
+            const float4 v0 = irm_ld4<VEC>(p + (long)c * N, n, N);
+            const float4 v1 = irm_ld4<VEC>(p + (long)(c + G) * N, n, N);
+            const float4 v2 = irm_ld4<VEC>(p + (long)(c + 2 * G) * N, n, N);
+            const float4 v3 = irm_ld4<VEC>(p + (long)(c + 3 * G) * N, n, N);
+            push(v0); push(v1); push(v2); push(v3);
         }
+        for (; c < C; c += G) push(irm_ld4<VEC>(p + (long)c * N, n, N));
     }
-    pm[w][lane] = mean;
-    pq[w][lane] = m2;
+    pm[g][q] = mean;
+    pq[g][q] = m2;
     __syncthreads();
-    if (w != 0 || n >= N) return;
-    // Chan's merge of (count, mean, M2) partials, fixed order 0,1,2,3
-    float na = (float)((C + 3) / 4);                 // channels seen by wave 0
-    for (int k = 1; k < 4; ++k) {
-        const int ck = (C - k + 3) / 4;              // channels k, k+4, ... < C
-        if (ck <= 0) continue;
+    if (g != 0 || n >= N) return;
+    // Chan's merge of (count, mean, M2) partials, fixed order 0, 1, ..., G - 1
+    float na = (float)((C + G - 1) / G);             // channels seen by group 0
+    for (int k = 1; k < G; ++k) {
+        const int ck = (C - k + G - 1) / G;          // channels k, k + G, ... < C
+        if (ck <= 0) break;
         const float nb = (float)ck, nt = na + nb;
-        const float4 mb = pm[k][lane], qb = pq[k][lane];
+        const float4 mb = pm[k][q], qb = pq[k][q];
         const float f = nb / nt, g2 = na * nb / nt;
         float d;
         d = mb.x - mean.x; mean.x += d * f; m2.x += qb.x + d * d * g2;
@@ -60,13 +72,21 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
     irm_st4<VEC>(s + N, n, N, rstd);
 }
 
+template <int PQ>
+static void ln_stats_launch(const float* x, long x_bs, float* stats, int B, int C, int N, float eps, bool vec,
+                            hipStream_t stream) {
+    dim3 grid(((N + 3) / 4 + PQ - 1) / PQ, B);
+    if (vec) hipLaunchKernelGGL((ln_stats_kernel<true, PQ>), grid, dim3(256), 0, stream, x, x_bs, stats, C, N, eps);
+    else hipLaunchKernelGGL((ln_stats_kernel<false, PQ>), grid, dim3(256), 0, stream, x, x_bs, stats, C, N, eps);
+}
+
 extern "C" int irm_ln_stats_f32(const float* x, long x_bs, float* stats, int B, int C, int N, float eps,
                                 hipStream_t stream) {
     if (!x || !stats || B <= 0 || C <= 0 || N <= 0 || B > 65535) return IRM_EINVAL;
-    dim3 grid(((N + 3) / 4 + 63) / 64, B);
     const bool vec = !(N & 3) && !(x_bs & 3) && irm_aligned16(x) && irm_aligned16(stats);
-    if (vec) hipLaunchKernelGGL(ln_stats_kernel<true>, grid, dim3(256), 0, stream, x, x_bs, stats, C, N, eps);
-    else hipLaunchKernelGGL(ln_stats_kernel<false>, grid, dim3(256), 0, stream, x, x_bs, stats, C, N, eps);
+    if (N >= 65536) ln_stats_launch<64>(x, x_bs, stats, B, C, N, eps, vec, stream);
+    else if (N >= 8192) ln_stats_launch<16>(x, x_bs, stats, B, C, N, eps, vec, stream);
+    else ln_stats_launch<4>(x, x_bs, stats, B, C, N, eps, vec, stream);
     return irm_launch_status();
 }
 

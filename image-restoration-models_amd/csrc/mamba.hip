@@ -66,12 +66,38 @@ struct ScanArgs {
 };
 
 // softplus with the hardware exp2/log2 (abs. error ~1e-7 on dt, far inside the 1e-3 output budget)
-__device__ __forceinline__ float irm_softplus(float x) { return x <= 20.0f ? __logf(1.0f + __expf(x)) : x; }
+// log1p by Kahan's correction (log(w) * e / (w - 1), w = 1 + e): dt spans 1e-3 .. 1e-1 in trained Mamba weights,
+// where log(1 + e) alone loses the low bits of e (relative error 6e-5 at e = 1e-3)
+__device__ __forceinline__ float irm_softplus(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+    const float w = 1.0f + e, dd = w - 1.0f;
+    const float l = __builtin_amdgcn_logf(w) * 0.69314718055994531f * (e * __builtin_amdgcn_rcpf(dd));
+    return x > 20.0f ? x : (dd == 0.0f ? e : l);
+}
 
+typedef const __attribute__((address_space(4))) float* sc_cf;     // wave-uniform data through the scalar cache
+typedef const __attribute__((address_space(4))) int* sc_ci;
+typedef float sc_v2 __attribute__((ext_vector_type(2)));
+template <int I> struct sc_ic { static constexpr int value = I; };
+template <int I0, int I1, class F>
+__device__ __forceinline__ void sc_for(F&& f) {
+    if constexpr (I0 < I1) { f(sc_ic<I0>{}); sc_for<I0 + 1, I1>(f); }
+}
+
+// The per-step row [dt_raw R | B N | C N] of a (direction, pixel) is wave-uniform: it is read with scalar loads
+// (s_load_dwordx8/16 through the constant cache) into SGPRs and used as the scalar operand of the vector
+// instructions - no broadcast instructions, and the vector memory pipe carries only u and y.  Scalar loads return
+// out of order, so there is one wait point per segment: [wait for segment s] [request segment s + 1] [compute s].
+// A segment is the whole row for N <= 8, else the dt part or 8 states' B and C (SGPR budget: two segments live).
+// States are processed in pairs with packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32): per pair 2 exp2 + 4
+// packed operations.  u is fetched one batch of TU steps ahead, the pixel ids two batches ahead.
 template <int N, int R, bool EMIT>
 __global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs a) {
     constexpr int J = R + 2 * N;
-    constexpr int TU = 8;                                     // time steps fetched together
+    constexpr int TU = N <= 8 ? 8 : 4;                        // time steps per batch (SGPR budget: 3 TU pixel ids)
+    constexpr int SG = N <= 8 ? N : 8;                        // states per segment
+    constexpr int NSEG = N <= 8 ? 1 : 1 + N / 8;              // segments per step
+    static_assert((TU * NSEG) % 2 == 0 && N % 2 == 0, "segment parity must be a compile-time constant");
     const int lane = threadIdx.x;
     const int c = blockIdx.x, kdb = blockIdx.y, b = blockIdx.z;
     const int k = kdb / a.DB, db = kdb % a.DB;
@@ -79,9 +105,10 @@ __global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs a) {
     const bool on = d < a.D;
     const int dc = on ? d : a.D - 1;                          // idle lanes shadow a valid channel
 
-    float Ac[N], wdt[R], h[N];
+    sc_v2 Ac[N / 2], h[N / 2];
+    float wdt[R];
 #pragma unroll
-    for (int n = 0; n < N; ++n) Ac[n] = a.A[((long)k * a.D + dc) * N + n] * 1.44269504088896341f;   // exp(x) = exp2(x log2 e)
+    for (int n = 0; n < N; ++n) Ac[n / 2][n % 2] = a.A[((long)k * a.D + dc) * N + n] * 1.44269504088896341f;   // exp(x) = exp2(x log2 e)
 #pragma unroll
     for (int r = 0; r < R; ++r) wdt[r] = a.dtw[((long)k * a.D + dc) * R + r];
     const float bias = a.dtb[k * a.D + dc];
@@ -90,58 +117,108 @@ __global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs a) {
     const long unit = (((long)b * 4 + k) * a.DB + db) * a.nchunk + c;
     float* st = a.state + (EMIT ? a.state_half : 0) + unit * N * 64;
 #pragma unroll
-    for (int n = 0; n < N; ++n) h[n] = EMIT ? st[n * 64 + lane] : 0.0f;
+    for (int n = 0; n < N; ++n) h[n / 2][n % 2] = EMIT ? st[n * 64 + lane] : 0.0f;
 
-    const int* ids = a.ids + (long)k * a.L;
-    const float* xT = a.xT + (long)b * a.L * a.D;
-    const float* pT = a.pT + (long)b * a.L * 4 * J + k * J;
-    float* yT = EMIT ? a.yT + ((long)b * 4 + k) * a.L * a.D : nullptr;
+    sc_ci ids = (sc_ci)(a.ids + (long)k * a.L);
+    const float* xT = a.xT + (long)b * a.L * a.D + dc;
+    sc_cf pT = (sc_cf)(a.pT + (long)b * a.L * 4 * J + k * J);
+    float* yT = EMIT ? a.yT + ((long)b * 4 + k) * a.L * a.D + d : nullptr;
     float sum_dt = 0.0f, sum_y = 0.0f;
 
-    // The per-step row [dt_raw | B | C] is wave-uniform.  It is fetched with ONE coalesced vector load
-    // per step (lane j holds element j) for TU steps ahead, and its elements are broadcast with
-    // v_readlane when used - nothing in the dependent chain waits on memory.
-    constexpr int JV = (J + 63) / 64;
     const int t0 = c * a.chunk, t1 = min(t0 + a.chunk, a.L);
-    for (int t = t0; t < t1; t += TU) {
-        int p[TU];
-        float u[TU], rowv[TU][JV];
+    struct Seg { float dt[R]; float B[SG]; float C[SG]; };
+    Seg buf[2];
+    auto request = [&](Seg& sg, int p, auto SI) {             // segment SI of the row of pixel p
+        constexpr int si = decltype(SI)::value;
+        sc_cf row = pT + (long)p * (4 * J);
+        if constexpr (si == 0) {
 #pragma unroll
-        for (int i = 0; i < TU; ++i) {
-            p[i] = __builtin_amdgcn_readfirstlane(ids[min(t + i, t1 - 1)]);
-            u[i] = xT[(long)p[i] * a.D + dc];
-#pragma unroll
-            for (int jv = 0; jv < JV; ++jv) rowv[i][jv] = pT[(long)p[i] * 4 * J + min(jv * 64 + lane, J - 1)];
+            for (int r = 0; r < R; ++r) sg.dt[r] = row[r];
         }
+        if constexpr (N <= 8 || si > 0) {
+            constexpr int n0 = N <= 8 ? 0 : 8 * (si - 1);
 #pragma unroll
-        for (int i = 0; i < TU; ++i) {
+            for (int n = 0; n < SG; ++n) { sg.B[n] = row[R + n0 + n]; sg.C[n] = row[R + N + n0 + n]; }
+        }
+    };
+    auto arrived = [&](Seg& sg, auto SI) {                    // the compiler waits (lgkmcnt(0)) before these uses
+        constexpr int si = decltype(SI)::value;
+        if constexpr (si == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) asm volatile("" : "+s"(sg.dt[r]));
+        }
+        if constexpr (N <= 8 || si > 0) {
+#pragma unroll
+            for (int n = 0; n < SG; ++n) { asm volatile("" : "+s"(sg.B[n])); asm volatile("" : "+s"(sg.C[n])); }
+        }
+    };
+    auto load_ids = [&](int (&p)[TU], int t) {
+#pragma unroll
+        for (int i = 0; i < TU; ++i) p[i] = ids[min(t + i, a.L - 1)];
+    };
+    auto load_u = [&](float (&u)[TU], const int (&p)[TU]) {
+#pragma unroll
+        for (int i = 0; i < TU; ++i) u[i] = xT[(long)p[i] * a.D];
+    };
+
+    int pc[TU], pn[TU], pnn[TU];
+    float uc[TU], un[TU];
+    load_ids(pc, t0);
+    load_ids(pn, t0 + TU);
+    load_u(uc, pc);
+    request(buf[0], pc[0], sc_ic<0>{});
+    for (int t = t0; t < t1; t += TU) {
+        load_ids(pnn, t + 2 * TU);
+        load_u(un, pn);
+        float dt = 0.f, du = 0.f;
+        sc_v2 y2 = {0.f, 0.f};
+        sc_for<0, TU * NSEG>([&](auto SS) {
+            constexpr int s = decltype(SS)::value, i = s / NSEG, si = s % NSEG, cur = s & 1;
+            constexpr int ni = (s + 1) / NSEG, nsi = (s + 1) % NSEG;       // the next segment of the stream
+            arrived(buf[cur], sc_ic<si>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ni < TU) request(buf[cur ^ 1], pc[ni], sc_ic<nsi>{});
+            else request(buf[cur ^ 1], pn[0], sc_ic<0>{});
+            __builtin_amdgcn_sched_barrier(0);
             if (t + i < t1) {
-#define IRM_ROW(j) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowv[i][(j) / 64]), (j) % 64))
-                float dt = bias;
+                const Seg& sg = buf[cur];
+                if constexpr (si == 0) {
+                    dt = bias;
 #pragma unroll
-                for (int r = 0; r < R; ++r) dt = fmaf(wdt[r], IRM_ROW(r), dt);
-                dt = irm_softplus(dt);
-                const float du = dt * u[i];
-                float y = dsk * u[i];
-#pragma unroll
-                for (int n = 0; n < N; ++n) {
-                    h[n] = fmaf(__builtin_amdgcn_exp2f(dt * Ac[n]), h[n], du * IRM_ROW(R + n));
-                    y = fmaf(h[n], IRM_ROW(R + N + n), y);
+                    for (int r = 0; r < R; ++r) dt = fmaf(wdt[r], sg.dt[r], dt);
+                    dt = irm_softplus(dt);
+                    du = dt * uc[i];
+                    y2 = (sc_v2){dsk * uc[i], 0.f};
+                    sum_dt += dt;
                 }
-#undef IRM_ROW
-                sum_dt += dt;
-                if (EMIT) {
-                    if (on) yT[(long)p[i] * a.D + d] = y;
-                    sum_y += y;
+                if constexpr (N <= 8 || si > 0) {
+                    constexpr int n0 = N <= 8 ? 0 : 8 * (si - 1);
+#pragma unroll
+                    for (int n = 0; n < SG; n += 2) {
+                        const sc_v2 x = (sc_v2){dt, dt} * Ac[(n0 + n) / 2];
+                        const sc_v2 e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                        const sc_v2 Bv = {sg.B[n], sg.B[n + 1]}, Cv = {sg.C[n], sg.C[n + 1]};
+                        h[(n0 + n) / 2] = e * h[(n0 + n) / 2] + (sc_v2){du, du} * Bv;
+                        if (EMIT) y2 = h[(n0 + n) / 2] * Cv + y2;
+                    }
+                }
+                if constexpr (si == NSEG - 1) {
+                    if (EMIT) {
+                        const float y = y2.x + y2.y;
+                        if (on) yT[(long)pc[i] * a.D] = y;
+                        sum_y += y;
+                    }
                 }
             }
-        }
+        });
+#pragma unroll
+        for (int i = 0; i < TU; ++i) { pc[i] = pn[i]; pn[i] = pnn[i]; uc[i] = un[i]; }
     }
     if (EMIT) {
         a.ysum[unit * 64 + lane] = on ? sum_y : 0.0f;
     } else {
 #pragma unroll
-        for (int n = 0; n < N; ++n) st[n * 64 + lane] = h[n];
+        for (int n = 0; n < N; ++n) st[n * 64 + lane] = h[n / 2][n % 2];
         a.sdt[unit * 64 + lane] = sum_dt;
     }
 }
@@ -234,7 +311,9 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ ysu
 }
 
 // combine: v[p][d] = sum_k y[k][p][d] * g[k][d]; LayerNorm over d (out_norm); * silu(z[d][p]); planar output.
-// One workgroup = 32 pixels; a wave normalises 8 pixels (lanes over d), the tile is transposed through LDS.
+// One workgroup = 4 PW pixels; a wave normalises PW pixels (lanes over d), the tile is transposed through LDS.
+// PW follows the plane size only (8 for large planes; 2 for the 64x64 / 32x32 levels of a single image, which
+// would otherwise run on 32 - 128 workgroups).
 struct CombArgs {
     const float* yT;      // [B][4][L][D]
     const float* gate;    // [B][4][D]
@@ -248,10 +327,11 @@ struct CombArgs {
     float eps;
 };
 
-template <int DV>      // DV = ceil(D / 64) values per lane
+template <int DV, int PW>      // DV = ceil(D / 64) values per lane
 __global__ __launch_bounds__(256) void combine_kernel(CombArgs a) {
-    extern __shared__ float tile[];                          // [D][33]
-    const int b = blockIdx.y, p0 = blockIdx.x * 32;
+    constexpr int PX = 4 * PW, TS = PX + 1;
+    extern __shared__ float tile[];                          // [D][PX + 1]
+    const int b = blockIdx.y, p0 = blockIdx.x * PX;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* g = a.gate + (long)b * 4 * a.D;
     float gk[4][DV], nw[DV], nb[DV];
@@ -263,10 +343,10 @@ __global__ __launch_bounds__(256) void combine_kernel(CombArgs a) {
         for (int k = 0; k < 4; ++k) gk[k][i] = g[k * a.D + d];
     }
     // 8 pixels per wave, all loads and both butterfly reductions of the 8 pixels interleaved (ILP)
-    float v[8][DV], s[8], sq[8];
+    float v[PW][DV], s[PW], sq[PW];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int p = min(p0 + wave * 8 + q, a.L - 1);
+    for (int q = 0; q < PW; ++q) {
+        const int p = min(p0 + wave * PW + q, a.L - 1);
         s[q] = 0.0f;
 #pragma unroll
         for (int i = 0; i < DV; ++i) {
@@ -284,9 +364,9 @@ __global__ __launch_bounds__(256) void combine_kernel(CombArgs a) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s[q] += __shfl_xor(s[q], o);
+        for (int q = 0; q < PW; ++q) s[q] += __shfl_xor(s[q], o);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < PW; ++q) {
         s[q] /= (float)a.D;                                  // mean
         sq[q] = 0.0f;
 #pragma unroll
@@ -298,27 +378,27 @@ __global__ __launch_bounds__(256) void combine_kernel(CombArgs a) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sq[q] += __shfl_xor(sq[q], o);
+        for (int q = 0; q < PW; ++q) sq[q] += __shfl_xor(sq[q], o);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int px = wave * 8 + q;
+    for (int q = 0; q < PW; ++q) {
+        const int px = wave * PW + q;
         const float rstd = 1.0f / sqrtf(sq[q] / (float)a.D + a.eps);
         if (p0 + px < a.L) {
 #pragma unroll
             for (int i = 0; i < DV; ++i) {
                 const int d = i * 64 + lane;
-                if (d < a.D) tile[d * 33 + px] = (v[q][i] - s[q]) * rstd * nw[i] + nb[i];
+                if (d < a.D) tile[d * TS + px] = (v[q][i] - s[q]) * rstd * nw[i] + nb[i];
             }
         }
     }
     __syncthreads();
     const float* z = a.z + (long)b * a.z_bs;
     float* out = a.out + (long)b * a.out_bs;
-    const int px = threadIdx.x & 31;
+    const int px = threadIdx.x % PX;
     if (p0 + px < a.L) {
-        for (int d = threadIdx.x >> 5; d < a.D; d += 8) {
+        for (int d = threadIdx.x / PX; d < a.D; d += 256 / PX) {
             const float zz = z[(long)d * a.L + p0 + px];
-            out[(long)d * a.L + p0 + px] = tile[d * 33 + px] * (zz / (1.0f + expf(-zz)));
+            out[(long)d * a.L + p0 + px] = tile[d * TS + px] * (zz / (1.0f + expf(-zz)));
         }
     }
 }
@@ -334,18 +414,18 @@ extern "C" int irm_losh_combine_f32(float* ysum, const float* gw, const float* g
     hipLaunchKernelGGL(gate_kernel, dim3((4 * D + 255) / 256, B), dim3(256), 0, stream, ysum, gw, gb, gate, D, DB,
                        nchunk, 1.0f / (float)L);
     CombArgs a{yT, gate, nw, nb, z, z_bs, out, out_bs, L, D, eps};
-    const size_t lds = (size_t)D * 33 * sizeof(float);
-    dim3 grid((L + 31) / 32, B);
+    const int pw = L >= 16384 ? 8 : 2;
+    const size_t lds = (size_t)D * (4 * pw + 1) * sizeof(float);
+    dim3 grid((L + 4 * pw - 1) / (4 * pw), B);
 #define IRM_COMB(DVV)                                                                                              \
     do {                                                                                                           \
-        static bool cfg = false;                                                                                   \
-        if (!cfg) {                                                                                                \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&combine_kernel<DVV>),                           \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)         \
-                return IRM_ELAUNCH;                                                                                \
-            cfg = true;                                                                                            \
+        if (pw == 8) {                                                                                             \
+            IRM_ALLOW_BIG_LDS((&combine_kernel<DVV, 8>));                                                          \
+            hipLaunchKernelGGL((combine_kernel<DVV, 8>), grid, dim3(256), lds, stream, a);                         \
+        } else {                                                                                                   \
+            IRM_ALLOW_BIG_LDS((&combine_kernel<DVV, 2>));                                                          \
+            hipLaunchKernelGGL((combine_kernel<DVV, 2>), grid, dim3(256), lds, stream, a);                         \
         }                                                                                                          \
-        hipLaunchKernelGGL(combine_kernel<DVV>, grid, dim3(256), lds, stream, a);                                  \
     } while (0)
     if (DB <= 2) IRM_COMB(2);
     else if (DB <= 3) IRM_COMB(3);

@@ -110,7 +110,7 @@ def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, 
         _chk(res, "res")
     mt = (M + 15) // 16
     if ct is None:
-        ct = _hip.choose_ct(mt)
+        ct = _hip.choose_ct(mt, blocks=(-(-N // 128) * B) if stats_out is None else 1 << 30)
     if ygroups is None:
         nchunks = -(-mt // ct)
         blocks = -(-N // 128) * B
