@@ -66,38 +66,34 @@ struct ScanArgs {
 };
 
 // softplus with the hardware exp2/log2 (abs. error ~1e-7 on dt, far inside the 1e-3 output budget)
-// log1p by Kahan's correction (log(w) * e / (w - 1), w = 1 + e): dt spans 1e-3 .. 1e-1 in trained Mamba weights,
-// where log(1 + e) alone loses the low bits of e (relative error 6e-5 at e = 1e-3)
+// softplus(x) = max(x, 0) + log1p(exp(-|x|)), branch free.  log1p by Kahan's correction (log(w) * e / (w - 1), w = 1 + e):
+// dt spans 1e-3 .. 1e-1 in trained Mamba weights, where log(1 + e) alone loses the low bits of e (6e-5 relative at 1e-3).
 __device__ __forceinline__ float irm_softplus(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+    const float e = __builtin_amdgcn_exp2f(fabsf(x) * -1.44269504088896341f);
     const float w = 1.0f + e, dd = w - 1.0f;
     const float l = __builtin_amdgcn_logf(w) * 0.69314718055994531f * (e * __builtin_amdgcn_rcpf(dd));
-    return x > 20.0f ? x : (dd == 0.0f ? e : l);
+    return fmaxf(x, 0.0f) + (dd == 0.0f ? e : l);
 }
 
-typedef const __attribute__((address_space(4))) float* sc_cf;     // wave-uniform data through the scalar cache
-typedef const __attribute__((address_space(4))) int* sc_ci;
 typedef float sc_v2 __attribute__((ext_vector_type(2)));
-template <int I> struct sc_ic { static constexpr int value = I; };
-template <int I0, int I1, class F>
-__device__ __forceinline__ void sc_for(F&& f) {
-    if constexpr (I0 < I1) { f(sc_ic<I0>{}); sc_for<I0 + 1, I1>(f); }
-}
+typedef float sc_v4 __attribute__((ext_vector_type(4)));
 
-// The per-step row [dt_raw R | B N | C N] of a (direction, pixel) is wave-uniform: it is read with scalar loads
-// (s_load_dwordx8/16 through the constant cache) into SGPRs and used as the scalar operand of the vector
-// instructions - no broadcast instructions, and the vector memory pipe carries only u and y.  Scalar loads return
-// out of order, so there is one wait point per segment: [wait for segment s] [request segment s + 1] [compute s].
-// A segment is the whole row for N <= 8, else the dt part or 8 states' B and C (SGPR budget: two segments live).
-// States are processed in pairs with packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32): per pair 2 exp2 + 4
-// packed operations.  u is fetched one batch of TU steps ahead, the pixel ids two batches ahead.
+// The per-step row [dt_raw R | B N | C N] of a (direction, pixel) is wave-uniform.  It is fetched with ONE coalesced
+// vector load per 64 elements (lane j holds element j) two batches of TU steps ahead - vector loads return in
+// order, so the prefetch depth is free of the one-wait-for-everything rule of scalar loads -, parked in a small
+// LDS ring private to the wave (no barriers: one wave, in-order LDS), and read back with same-address (broadcast)
+// ds_read_b128: four row elements per instruction arrive in VGPRs of every lane and feed packed fp32 instructions
+// directly - no v_readlane, no SGPR budget.  States go in pairs: per pair 2 exp2 + 4 packed operations
+// (v_pk_mul_f32 / v_pk_fma_f32).  Pixel ids travel as one vector load per batch (lane i = step i), three
+// batches ahead; u one load per step, two batches ahead.
 template <int N, int R, bool EMIT>
-__global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs a) {
-    constexpr int J = R + 2 * N;
-    constexpr int TU = N <= 8 ? 8 : 4;                        // time steps per batch (SGPR budget: 3 TU pixel ids)
-    constexpr int SG = N <= 8 ? N : 8;                        // states per segment
-    constexpr int NSEG = N <= 8 ? 1 : 1 + N / 8;              // segments per step
-    static_assert((TU * NSEG) % 2 == 0 && N % 2 == 0, "segment parity must be a compile-time constant");
+__global__ __launch_bounds__(64, (N <= 8 ? 4 : N == 16 ? 3 : 2)) void scan_chunk_kernel(ScanArgs a) {   // (waves per SIMD: caps the
+    constexpr int J = R + 2 * N, JV = (J + 63) / 64;                                                    // scheduler's read hoisting)
+    constexpr int TU = 8;                                     // time steps per batch
+    constexpr int RP = (R + 3) & ~3;                          // LDS row: [dt_raw, padded to 16 bytes | B | C]
+    constexpr int JS = RP + 2 * N;
+    static_assert(N % 4 == 0, "states are read four at a time");
+    __shared__ __attribute__((aligned(16))) float ring[2][TU][JS];
     const int lane = threadIdx.x;
     const int c = blockIdx.x, kdb = blockIdx.y, b = blockIdx.z;
     const int k = kdb / a.DB, db = kdb % a.DB;
@@ -119,100 +115,97 @@ __global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs a) {
 #pragma unroll
     for (int n = 0; n < N; ++n) h[n / 2][n % 2] = EMIT ? st[n * 64 + lane] : 0.0f;
 
-    sc_ci ids = (sc_ci)(a.ids + (long)k * a.L);
+    const int* ids = a.ids + (long)k * a.L;
     const float* xT = a.xT + (long)b * a.L * a.D + dc;
-    sc_cf pT = (sc_cf)(a.pT + (long)b * a.L * 4 * J + k * J);
+    const float* pT = a.pT + (long)b * a.L * 4 * J + k * J;
     float* yT = EMIT ? a.yT + ((long)b * 4 + k) * a.L * a.D + d : nullptr;
     float sum_dt = 0.0f, sum_y = 0.0f;
-
     const int t0 = c * a.chunk, t1 = min(t0 + a.chunk, a.L);
-    struct Seg { float dt[R]; float B[SG]; float C[SG]; };
-    Seg buf[2];
-    auto request = [&](Seg& sg, int p, auto SI) {             // segment SI of the row of pixel p
-        constexpr int si = decltype(SI)::value;
-        sc_cf row = pT + (long)p * (4 * J);
-        if constexpr (si == 0) {
+
+    // element e = 64 jv + lane of a row -> its LDS position
+    int epos[JV], eidx[JV];
 #pragma unroll
-            for (int r = 0; r < R; ++r) sg.dt[r] = row[r];
-        }
-        if constexpr (N <= 8 || si > 0) {
-            constexpr int n0 = N <= 8 ? 0 : 8 * (si - 1);
+    for (int jv = 0; jv < JV; ++jv) {
+        const int e = jv * 64 + lane;
+        eidx[jv] = min(e, J - 1);
+        epos[jv] = e < R ? e : (e < J ? e + (RP - R) : -1);
+    }
+    auto load_ids = [&](int t) { return ids[min(t + (lane & (TU - 1)), a.L - 1)]; };
+    auto load_batch = [&](float (&rw)[TU][JV], float (&u)[TU], int idv) {
 #pragma unroll
-            for (int n = 0; n < SG; ++n) { sg.B[n] = row[R + n0 + n]; sg.C[n] = row[R + N + n0 + n]; }
-        }
-    };
-    auto arrived = [&](Seg& sg, auto SI) {                    // the compiler waits (lgkmcnt(0)) before these uses
-        constexpr int si = decltype(SI)::value;
-        if constexpr (si == 0) {
+        for (int i = 0; i < TU; ++i) {
+            const int p = __builtin_amdgcn_readlane(idv, i);
+            u[i] = xT[(long)p * a.D];
 #pragma unroll
-            for (int r = 0; r < R; ++r) asm volatile("" : "+s"(sg.dt[r]));
-        }
-        if constexpr (N <= 8 || si > 0) {
-#pragma unroll
-            for (int n = 0; n < SG; ++n) { asm volatile("" : "+s"(sg.B[n])); asm volatile("" : "+s"(sg.C[n])); }
+            for (int jv = 0; jv < JV; ++jv) rw[i][jv] = pT[(long)p * (4 * J) + eidx[jv]];
         }
     };
-    auto load_ids = [&](int (&p)[TU], int t) {
+    auto park = [&](const float (&rw)[TU][JV], int slot) {
 #pragma unroll
-        for (int i = 0; i < TU; ++i) p[i] = ids[min(t + i, a.L - 1)];
-    };
-    auto load_u = [&](float (&u)[TU], const int (&p)[TU]) {
+        for (int i = 0; i < TU; ++i)
 #pragma unroll
-        for (int i = 0; i < TU; ++i) u[i] = xT[(long)p[i] * a.D];
+            for (int jv = 0; jv < JV; ++jv)
+                if (epos[jv] >= 0) ring[slot][i][epos[jv]] = rw[i][jv];
     };
 
-    int pc[TU], pn[TU], pnn[TU];
-    float uc[TU], un[TU];
-    load_ids(pc, t0);
-    load_ids(pn, t0 + TU);
-    load_u(uc, pc);
-    request(buf[0], pc[0], sc_ic<0>{});
-    for (int t = t0; t < t1; t += TU) {
-        load_ids(pnn, t + 2 * TU);
-        load_u(un, pn);
-        float dt = 0.f, du = 0.f;
-        sc_v2 y2 = {0.f, 0.f};
-        sc_for<0, TU * NSEG>([&](auto SS) {
-            constexpr int s = decltype(SS)::value, i = s / NSEG, si = s % NSEG, cur = s & 1;
-            constexpr int ni = (s + 1) / NSEG, nsi = (s + 1) % NSEG;       // the next segment of the stream
-            arrived(buf[cur], sc_ic<si>{});
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ni < TU) request(buf[cur ^ 1], pc[ni], sc_ic<nsi>{});
-            else request(buf[cur ^ 1], pn[0], sc_ic<0>{});
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + i < t1) {
-                const Seg& sg = buf[cur];
-                if constexpr (si == 0) {
-                    dt = bias;
+    int id0 = load_ids(t0), id1 = load_ids(t0 + TU), id2 = load_ids(t0 + 2 * TU);
+    float u0[TU], u1[TU], u2[TU], r1[TU][JV], r2[TU][JV];
+    load_batch(r1, u0, id0);
+    park(r1, 0);
+    load_batch(r1, u1, id1);
+    int slot = 0;
+    for (int t = t0; t < t1; t += TU, slot ^= 1) {
+        const int id3 = load_ids(t + 3 * TU);
+        load_batch(r2, u2, id2);
+        park(r1, slot ^ 1);                                   // batch t + TU (requested one iteration ago)
 #pragma unroll
-                    for (int r = 0; r < R; ++r) dt = fmaf(wdt[r], sg.dt[r], dt);
-                    dt = irm_softplus(dt);
-                    du = dt * uc[i];
-                    y2 = (sc_v2){dsk * uc[i], 0.f};
-                    sum_dt += dt;
-                }
-                if constexpr (N <= 8 || si > 0) {
-                    constexpr int n0 = N <= 8 ? 0 : 8 * (si - 1);
+        for (int i = 0; i < TU; ++i) {
+            // steps past the chunk end run with dt = 0 (decay 1, input 0: the state is untouched) and store nothing:
+            // the batch stays one straight-line block, free of per-step branches
+            const bool live = t + i < t1;
+            const float* row = &ring[slot][i][0];
+            float dt = bias;
 #pragma unroll
-                    for (int n = 0; n < SG; n += 2) {
-                        const sc_v2 x = (sc_v2){dt, dt} * Ac[(n0 + n) / 2];
-                        const sc_v2 e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-                        const sc_v2 Bv = {sg.B[n], sg.B[n + 1]}, Cv = {sg.C[n], sg.C[n + 1]};
-                        h[(n0 + n) / 2] = e * h[(n0 + n) / 2] + (sc_v2){du, du} * Bv;
-                        if (EMIT) y2 = h[(n0 + n) / 2] * Cv + y2;
-                    }
-                }
-                if constexpr (si == NSEG - 1) {
-                    if (EMIT) {
-                        const float y = y2.x + y2.y;
-                        if (on) yT[(long)pc[i] * a.D] = y;
-                        sum_y += y;
-                    }
+            for (int r = 0; r < RP; r += 4) {
+                const sc_v4 q = *reinterpret_cast<const sc_v4*>(row + r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (r + e < R) dt = fmaf(wdt[r + e], q[e], dt);
+            }
+            dt = irm_softplus(dt) * (live ? 1.0f : 0.0f);
+            const float du = dt * u0[i];
+            sc_v2 y2 = {dsk * u0[i], 0.f};
+#pragma unroll
+            for (int n = 0; n < N; n += 4) {
+                const sc_v4 Bq = *reinterpret_cast<const sc_v4*>(row + RP + n);
+                const sc_v4 Cq = *reinterpret_cast<const sc_v4*>(row + RP + N + n);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int m = (n + 2 * hh) / 2;
+                    const sc_v2 x = (sc_v2){dt, dt} * Ac[m];
+                    const sc_v2 e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                    const sc_v2 Bv = {Bq[2 * hh], Bq[2 * hh + 1]}, Cv = {Cq[2 * hh], Cq[2 * hh + 1]};
+                    h[m] = e * h[m] + (sc_v2){du, du} * Bv;
+                    if (EMIT) y2 = h[m] * Cv + y2;
                 }
             }
-        });
+            sum_dt += dt;
+            if (EMIT) {
+                const float y = live ? y2.x + y2.y : 0.0f;
+                const int p = __builtin_amdgcn_readlane(id0, i);
+                if (on && live) yT[(long)p * a.D] = y;
+                sum_y += y;
+            }
+            // without this the scheduler hoists the LDS reads of all 8 steps to the top (388 VGPRs at N = 32)
+            if (i & 1) __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-        for (int i = 0; i < TU; ++i) { pc[i] = pn[i]; pn[i] = pnn[i]; uc[i] = un[i]; }
+        for (int i = 0; i < TU; ++i) {
+            u0[i] = u1[i]; u1[i] = u2[i];
+#pragma unroll
+            for (int jv = 0; jv < JV; ++jv) r1[i][jv] = r2[i][jv];
+        }
+        id0 = id1; id1 = id2; id2 = id3;
     }
     if (EMIT) {
         a.ysum[unit * 64 + lane] = on ? sum_y : 0.0f;
@@ -224,53 +217,92 @@ __global__ __launch_bounds__(64) void scan_chunk_kernel(ScanArgs a) {
 }
 
 // phase B: carry the state across the chunks of one (batch, direction, channel block):
-// h_in[0] = 0, h_in[c+1] = exp(A * sum_dt[c]) * h_in[c] + h_end[c].  Inputs and outputs are separate
-// buffers so the loads of the next chunks are in flight while the dependent chain advances.
+// h_in[0] = 0, h_in[c+1] = exp(A * sum_dt[c]) * h_in[c] + h_end[c].  A serial walk over all chunks is a chain of
+// several hundred dependent steps on a handful of waves (it used to cost as much as a scan phase), so the chunks
+// are cut into 16 groups, one wave each: the wave composes its group (decay = exp(A * sum of the group's dt), state
+// from zero), the 16 composites meet in LDS, every wave folds the groups before it (<= 15 LDS steps) and walks its
+// group again to emit the initial states.  A workgroup owns 8 states of 64 channels.
 template <int N>
-__global__ __launch_bounds__(64) void scan_carry_kernel(ScanArgs a) {
-    const int lane = threadIdx.x;
-    const int kdb = blockIdx.x, b = blockIdx.y;
+__global__ __launch_bounds__(1024) void scan_carry_kernel(ScanArgs a) {
+    constexpr int NB = N < 8 ? N : 8, G = 16;
+    __shared__ float comp[G][NB + 1][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int kdb = blockIdx.x, b = blockIdx.y, n0 = blockIdx.z * NB;
     const int k = kdb / a.DB, db = kdb % a.DB;
     const int dc = min(db * 64 + lane, a.D - 1);
-    float Ac[N], h[N];
+    float Ac[NB], h[NB];
 #pragma unroll
-    for (int n = 0; n < N; ++n) { Ac[n] = a.A[((long)k * a.D + dc) * N + n]; h[n] = 0.0f; }
+    for (int n = 0; n < NB; ++n) { Ac[n] = a.A[((long)k * a.D + dc) * N + n0 + n]; h[n] = 0.0f; }
     const long base = (((long)b * 4 + k) * a.DB + db) * a.nchunk;
-    const float* __restrict__ hend = a.state + base * N * 64 + lane;
-    float* __restrict__ hin = a.state + a.state_half + base * N * 64 + lane;
+    const float* __restrict__ hend = a.state + base * N * 64 + n0 * 64 + lane;
+    float* __restrict__ hin = a.state + a.state_half + base * N * 64 + n0 * 64 + lane;
     const float* __restrict__ sdt = a.sdt + base * 64 + lane;
+    const int cpg = (a.nchunk + G - 1) / G;
+    const int c0 = min(g * cpg, a.nchunk), c1 = min(c0 + cpg, a.nchunk);
+    float ssum = 0.0f;
 #pragma unroll 4
-    for (int c = 0; c < a.nchunk; ++c) {
+    for (int c = c0; c < c1; ++c) {
         const float s = sdt[(long)c * 64];
-        float e[N];
+        float e[NB];
 #pragma unroll
-        for (int n = 0; n < N; ++n) e[n] = hend[((long)c * N + n) * 64];
+        for (int n = 0; n < NB; ++n) e[n] = hend[((long)c * N + n) * 64];
 #pragma unroll
-        for (int n = 0; n < N; ++n) {
+        for (int n = 0; n < NB; ++n) h[n] = fmaf(__expf(Ac[n] * s), h[n], e[n]);
+        ssum += s;
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) comp[g][n][lane] = h[n];
+    comp[g][NB][lane] = ssum;
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NB; ++n) h[n] = 0.0f;
+    for (int j = 0; j < g; ++j) {
+        const float s = comp[j][NB][lane];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) h[n] = fmaf(__expf(Ac[n] * s), h[n], comp[j][n][lane]);
+    }
+#pragma unroll 4
+    for (int c = c0; c < c1; ++c) {
+        const float s = sdt[(long)c * 64];
+        float e[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) e[n] = hend[((long)c * N + n) * 64];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
             hin[((long)c * N + n) * 64] = h[n];
             h[n] = fmaf(__expf(Ac[n] * s), h[n], e[n]);
         }
     }
 }
 
-// per (batch, direction, channel block): ysum[chunk 0] <- sum over chunks (fixed order: 4 interleaved
-// partial sums combined in wave order), so the gate reads one value per channel
-__global__ __launch_bounds__(256) void ysum_reduce_kernel(float* __restrict__ ysum, int nchunk) {
-    __shared__ float part[4][64];
+// per (batch, direction, channel block): ysum[chunk 0] <- sum over chunks (fixed order: 16 interleaved partial
+// sums, four loads in flight each, combined in wave order), so the gate reads one value per channel
+__global__ __launch_bounds__(1024) void ysum_reduce_kernel(float* __restrict__ ysum, int nchunk) {
+    __shared__ float part[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float* p = ysum + (long)blockIdx.x * nchunk * 64 + lane;
     float s = 0.0f;
-    for (int c = w; c < nchunk; c += 4) s += p[(long)c * 64];
+    int c = w;
+    for (; c + 48 < nchunk; c += 64) {
+        const float v0 = p[(long)c * 64], v1 = p[(long)(c + 16) * 64], v2 = p[(long)(c + 32) * 64], v3 = p[(long)(c + 48) * 64];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; c < nchunk; c += 16) s += p[(long)c * 64];
     part[w][lane] = s;
     __syncthreads();
-    if (w == 0) p[0] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (w == 0) {
+        float t = part[0][lane];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) t += part[j][lane];
+        p[0] = t;
+    }
 }
 
 template <int N, int R>
 static int scan_launch(const ScanArgs& a, int B, hipStream_t stream) {
-    dim3 g1(a.nchunk, 4 * a.DB, B), g2(4 * a.DB, B);
+    dim3 g1(a.nchunk, 4 * a.DB, B), g2(4 * a.DB, B, N < 8 ? 1 : N / 8);
     hipLaunchKernelGGL((scan_chunk_kernel<N, R, false>), g1, dim3(64), 0, stream, a);
-    hipLaunchKernelGGL((scan_carry_kernel<N>), g2, dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((scan_carry_kernel<N>), g2, dim3(1024), 0, stream, a);
     hipLaunchKernelGGL((scan_chunk_kernel<N, R, true>), g1, dim3(64), 0, stream, a);
     return irm_launch_status();
 }
@@ -410,7 +442,7 @@ extern "C" int irm_losh_combine_f32(float* ysum, const float* gw, const float* g
     if (!ysum || !gw || !gb || !gate || !yT || !nw || !nb || !z || !out) return IRM_EINVAL;
     if (B <= 0 || L <= 0 || D <= 0 || nchunk <= 0 || B > 65535 || D > 1024) return IRM_EINVAL;
     const int DB = (D + 63) / 64;
-    hipLaunchKernelGGL(ysum_reduce_kernel, dim3(B * 4 * DB), dim3(256), 0, stream, ysum, nchunk);
+    hipLaunchKernelGGL(ysum_reduce_kernel, dim3(B * 4 * DB), dim3(1024), 0, stream, ysum, nchunk);
     hipLaunchKernelGGL(gate_kernel, dim3((4 * D + 255) / 256, B), dim3(256), 0, stream, ysum, gw, gb, gate, D, DB,
                        nchunk, 1.0f / (float)L);
     CombArgs a{yT, gate, nw, nb, z, z_bs, out, out_bs, L, D, eps};

@@ -304,11 +304,12 @@ def transpose(src: torch.Tensor, dst: torch.Tensor, R: int, C: int):
 
 
 def scan_plan(B: int, L: int, D: int):
-    """(chunk, nchunk, DB): time steps per wave; a wave is one sequential recurrence, so the scan is
-    latency bound per wave - aim at ~4 waves per SIMD (4k waves) before growing the chunk."""
+    """(chunk, nchunk, DB): time steps per wave.  A wave is one sequential recurrence; measured on the five MaIRUNet
+    shapes of a 256x256 image (tools/bench_scan.py) the scan is fastest with ~3 waves per SIMD (3k waves: all
+    resident at once, none queued behind a full SIMD) and chunks of at least 32 steps (whole batches of 8)."""
     DB = (D + 63) // 64
-    nchunk = max(1, min(-(-L // 32), -(-4096 // (B * 4 * DB))))
-    chunk = max(32, -(-(-(-L // nchunk)) // 4) * 4)
+    nchunk = max(1, min(-(-L // 32), -(-3072 // (B * 4 * DB))))
+    chunk = max(32, -(-(-(-L // nchunk)) // 8) * 8)
     return chunk, -(-L // chunk), DB
 
 
