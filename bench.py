@@ -347,6 +347,12 @@ def main():
                            {"IRM_GEMM_EXACT": "1"})
             out["value_exact_f32"] = None if ex is None else ex["value"]
             out["value_exact_f32_note"] = "IRM_GEMM_EXACT=1: every GEMM on the f32-input MFMA, no fused branch kernels; 5 steps"
+            ts = child_leg(["--steps", str(max(args.steps, 8)), "--warmup", "2", "--no-cpu-baseline", "--no-kernel-timer",
+                            "--no-legs", "--streams", "2"], {})
+            out["value_two_streams"] = None if ts is None else ts["value"]
+            out["value_two_streams_note"] = ("model.num_streams = 2: the frame's tiles run as two groups on two HIP streams, so "
+                                             "the tails of ~600 launches overlap; same results.  Not `value`: per-launch events "
+                                             "of overlapping kernels are not kernel durations, so the roofline leg stays on one stream")
             pc = child_leg(["--leg", "pcie", "--steps", "8", "--warmup", "2"], {})
             out["value_pcie_inclusive"] = None if pc is None else pc["value"]
             out["value_pcie_inclusive_note"] = ("get_model_prediction(model, numpy_frame, device, **patch_config): uint8 frame in "

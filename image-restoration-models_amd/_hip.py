@@ -32,6 +32,7 @@ SIGNATURES = {
     "irm_gdfn_fused_f16x3_f32": [_P, _P, _P, _P, _L, _P, _L, _I, _F, _F, _F, _I, _I, _I, _I, _I, _P],
     "irm_qkv_dw_fused_f16x3_f32": [_P, _P, _L, _P, _L, _I, _F, _F, _I, _I, _I, _I, _I, _P],
     "irm_mdta_gram_f32": [_P, _L, _P, _I, _I, _I, _I, _I, _P],
+    "irm_mdta_gram_f16x3_f32": [_P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
     "irm_mdta_finalize_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "irm_mdta_finalize_f16x3_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "irm_conv3x3_f32": [_P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -143,6 +144,50 @@ def split_is_safe(w: torch.Tensor, lnw=None, lnb=None) -> bool:
         if not (bound < 2.0 ** 15):
             return False
     return True
+
+
+def param_key(module):
+    """Cheap per-forward fingerprint of a module's weights: the parameter tuple is cached on the module, the walk reads
+    only `p._version` (in-place updates, load_state_dict) plus the device and storage address of the first and last
+    parameter (`.to()` / `.float()` swap every storage together).  load_state_dict(assign=True) replaces the Parameter
+    objects themselves: a post hook drops the cached tuple."""
+    d = module.__dict__
+    pl = d.get("_irm_plist")
+    if pl is None:
+        pl = tuple(module.parameters())
+        d["_irm_plist"] = pl
+        if not d.get("_irm_hooked"):
+            d["_irm_hooked"] = True
+            module.register_load_state_dict_post_hook(lambda m, _keys: m.__dict__.pop("_irm_plist", None))
+    if not pl:
+        return (None, 0, 0)
+    ver = 0
+    for p in pl:
+        ver += p._version
+    return (str(pl[0].device), pl[0].data_ptr() ^ (pl[-1].data_ptr() << 1), ver)
+
+
+def gram_scales(qkv_w, qkv_b, dw_w, dw_b, lnw, lnb, ln_with_bias: bool):
+    """Per-channel power-of-two operand scales [2C] of irm_mdta_gram_f16x3_f32 (q channels, then k channels), or None
+    when no static bound exists.  The scale must make overflow IMPOSSIBLE for any input, so it comes from a bound:
+    a WithBias LayerNorm output obeys |y_j| <= sqrt(C - 1) |w_j| + |b_j| (a normalised deviation of C samples cannot
+    exceed sqrt(C - 1)), hence |qkv_c| <= sum_j |W_cj| (...) + |bias_c| and |dw(qkv)_c| <= sum_taps |t| * that + |dw bias_c|.
+    scale_c = 2^floor(log2(2^14.8 / bound_c)).  Typical activations sit ~2^-8 below the bound: their hi part keeps 11
+    bits and the lo part stays far above the fp16 subnormals.  A BiasFree LayerNorm (x / sigma, mean not removed) has no
+    such bound: the caller keeps the f32-input MFMA Gram there."""
+    if not ln_with_bias or lnw is None:
+        return None
+    w = qkv_w.detach().reshape(qkv_w.shape[0], -1).double()
+    C = w.shape[1]
+    a = (C - 1) ** 0.5 * lnw.detach().double().abs() + (lnb.detach().double().abs() if lnb is not None else 0.0)
+    pre = w.abs() @ a + (qkv_b.detach().double().abs() if qkv_b is not None else 0.0)
+    taps = dw_w.detach().reshape(dw_w.shape[0], -1).double().abs().sum(1)
+    bound = (taps * pre + (dw_b.detach().double().abs() if dw_b is not None else 0.0))[:2 * C]
+    if not bool(torch.isfinite(bound).all()):
+        return None
+    e = torch.floor(torch.log2(torch.tensor(2.0 ** 14.8, dtype=torch.float64) / bound.clamp_min(1e-300)))
+    e = torch.where(bound > 0, e, torch.zeros_like(e)).clamp(-100, 100)
+    return torch.pow(torch.tensor(2.0, dtype=torch.float64), e).float().contiguous()
 
 
 def pack_conv3x3_weight(w: torch.Tensor) -> torch.Tensor:

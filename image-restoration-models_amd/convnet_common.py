@@ -18,11 +18,7 @@ class PackedCache:
         self.module, self.build, self.key, self.value = module, build, None, None
 
     def get(self):
-        ver, dev = 0, None
-        for p in self.module.parameters():
-            dev = p.device
-            ver += p._version + (p.data_ptr() & 0xFFFF)
-        key = (str(dev), ver)
+        key = _hip.param_key(self.module)
         if self.value is None or key != self.key:
             self.value, self.key = self.build(), key
         return self.value

@@ -85,7 +85,7 @@ extern "C" int irm_ln_stats_f32(const float* x, long x_bs, float* stats, int B, 
     if (!x || !stats || B <= 0 || C <= 0 || N <= 0 || B > 65535) return IRM_EINVAL;
     const bool vec = !(N & 3) && !(x_bs & 3) && irm_aligned16(x) && irm_aligned16(stats);
     if (N >= 65536) ln_stats_launch<64>(x, x_bs, stats, B, C, N, eps, vec, stream);
-    else if (N >= 8192) ln_stats_launch<16>(x, x_bs, stats, B, C, N, eps, vec, stream);
+    else if (N >= 2048) ln_stats_launch<16>(x, x_bs, stats, B, C, N, eps, vec, stream);
     else ln_stats_launch<4>(x, x_bs, stats, B, C, N, eps, vec, stream);
     return irm_launch_status();
 }

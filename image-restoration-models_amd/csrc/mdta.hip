@@ -287,6 +287,207 @@ __global__ __launch_bounds__(256, 2) void mdta_gram_ring_kernel(GramArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same Gram pass as an fp32 emulation on the fp16 matrix cores (irm_mdta_gram_f16x3_f32): the f32-input MFMA
+// above needs 2304 matrix cycles per wave and 24 KiB stage - 6.4 TB/s at best with two workgroups per CU -, the
+// emulation 432 (27 v_mfma_f32_16x16x32_f16) plus ~400 cycles of vector work for the hi/lo split, so the sweep over
+// q, k becomes a memory stream.  Same LDS-DMA ring and piece rotation as mdta_gram_ring_kernel; an operand fragment
+// (row, 8 consecutive pixels) is two conflict-free ds_read_b128, scaled by the row's power-of-two factor
+// (`scale`, host side: 2^14-ish / a static bound of |q_c|, |k_c| - exact), split into fp16 hi + lo, and multiplied
+// as lo*hi + hi*lo + hi*hi with fp32 accumulation.  The squared norms stay on the fp32 vector pipe.  Records leave
+// the kernel unscaled (power-of-two factors: exact), so the reduction and the softmax are unchanged.
+//   T = 6 (c = 96): BP = 32, wave (wa, wb) owns the 48 x 48 quadrant (wa, wb), one 32-pixel k-step per stage.
+//   T = 3 (c = 48): BP = 64, wave w takes the 32-pixel half w & 1 of the stage and q tiles {0, 1} (w < 2) or {2}.
+typedef _Float16 gr_h8 __attribute__((ext_vector_type(8)));
+
+template <int T, int NS>
+__global__ __launch_bounds__(256, 2) void mdta_gram_f16x3_kernel(GramArgs a, const float* __restrict__ scale) {
+    constexpr int c = 16 * T;
+    constexpr int BP = T == 3 ? 64 : 32;           // pixels per stage
+    constexpr int CPR = BP / 4;                    // 16-byte pieces per row segment
+    constexpr int RPB = 64 / CPR;                  // rows per 1 KiB DMA instruction
+    constexpr int NI = 2 * c / RPB;                // DMA instructions per stage (24)
+    constexpr int LPS = NI / 4;                    // per wave (6)
+    constexpr int STG = NI * 256;                  // floats per stage
+    static_assert((NS - 2) * LPS <= 63, "vmcnt field");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int head = blockIdx.x / a.nchunk, chunk_id = blockIdx.x % a.nchunk;
+    const int nbeg = chunk_id * a.chunk;
+    const int S = (min(nbeg + a.chunk, a.N) - nbeg) / BP;
+    const float* base = a.qkv + (long)b * a.bs + nbeg;
+
+    const float* src[LPS];
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) {
+        const int row = RPB * (4 * j + wave) + lane / CPR, p = lane % CPR;
+        const int rot = (T == 3 ? row : row >> 1) & (CPR - 1);
+        const int ch = row < c ? head * c + row : a.C + head * c + (row - c);
+        src[j] = base + (long)ch * a.N + 4 * ((p - rot) & (CPR - 1));
+    }
+    auto issue = [&](int s) {
+        float* dst = smem + (s % NS) * STG + wave * 256;
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long)s * BP),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+        }
+    };
+
+    // this wave's tiles
+    const int wa = wave >> 1, wb = wave & 1;
+    constexpr int NQ = T == 3 ? 2 : 3;                                  // q tiles held (T = 3, w >= 2: only the first is used)
+    const int qt0 = T == 3 ? 2 * wa : 3 * wa, kt0 = T == 3 ? 0 : 3 * wb;
+    const int nq_used = T == 3 ? (wa ? 1 : 2) : 3;
+    const bool do_q = T == 3 || wa != wb, do_k = T == 3 ? wa == 1 : wa == wb;   // who accumulates which squared norms
+    // fragment addresses: row R, pixels 8 g .. 8 g + 7 of this wave's 32-pixel k-step = source pieces ph + 2 g, + 1
+    const int rot = T == 3 ? i : i >> 1;
+    const int ph = T == 3 ? 8 * wb : 0;
+    const int o0 = 4 * ((ph + 2 * g + rot) & (CPR - 1)), o1 = 4 * ((ph + 2 * g + 1 + rot) & (CPR - 1));
+    float sq[NQ], sk[3];
+#pragma unroll
+    for (int m = 0; m < NQ; ++m) sq[m] = scale[head * c + min(16 * (qt0 + m), c - 16) + i];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) sk[m] = scale[a.C + head * c + 16 * (kt0 + m) + i];
+
+    f32x4 acc[NQ][3];
+    float nq[NQ], nk[3];
+#pragma unroll
+    for (int x = 0; x < NQ; ++x) {
+        nq[x] = 0.f;
+#pragma unroll
+        for (int y = 0; y < 3; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int y = 0; y < 3; ++y) nk[y] = 0.f;
+
+    auto fragment = [&](const float* rowp, float sc, bool norm, float& nacc, gr_h8& hi, gr_h8& lo) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(rowp + o0);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(rowp + o1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = e < 4 ? v0[e] : v1[e - 4];
+            if (norm) nacc = fmaf(x, x, nacc);
+            const float xs = x * sc;                       // power-of-two factor: exact
+            const _Float16 h = (_Float16)xs;
+            hi[e] = h;
+            lo[e] = (_Float16)(xs - (float)h);
+        }
+    };
+
+#pragma unroll
+    for (int j = 0; j < NS - 1; ++j)
+        if (j < S) issue(j);
+
+    for (int s = 0; s < S; ++s) {
+        const int rem = min(NS - 2, S - 1 - s);
+        if (rem >= NS - 2 && NS >= 3) gram_wait_vmcnt<(NS - 2) * LPS>();
+        else gram_wait_vmcnt<0>();
+        asm volatile("s_barrier" ::: "memory");
+        if (s + NS - 1 < S) issue(s + NS - 1);
+        const float* xb = smem + (s % NS) * STG + i * BP;
+        gr_h8 qh[NQ], ql[NQ], kh[3], kl[3];
+#pragma unroll
+        for (int m = 0; m < NQ; ++m)
+            if (m < nq_used) fragment(xb + (qt0 + m) * 16 * BP, sq[m], do_q, nq[m], qh[m], ql[m]);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) fragment(xb + (c + (kt0 + m) * 16) * BP, sk[m], do_k, nk[m], kh[m], kl[m]);
+#pragma unroll
+        for (int x = 0; x < NQ; ++x) {
+            if (x < nq_used) {
+#pragma unroll
+                for (int y = 0; y < 3; ++y) {
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql[x], kh[y], acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[x], kl[y], acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[x], kh[y], acc[x][y], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // squared norms: sum the 4 pixel groups (lanes i, i+16, i+32, i+48)
+#pragma unroll
+    for (int m = 0; m < NQ; ++m) { nq[m] += __shfl_xor(nq[m], 16); nq[m] += __shfl_xor(nq[m], 32); }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { nk[m] += __shfl_xor(nk[m], 16); nk[m] += __shfl_xor(nk[m], 32); }
+    constexpr int REC = c * c + 2 * c;
+    float* out = a.part + (((long)b * a.heads + head) * a.nchunk + chunk_id) * REC;
+    // undo the operand scales (exact): element (q row, k row) by 1 / (s_q s_k)
+    float isk[3];
+#pragma unroll
+    for (int y = 0; y < 3; ++y) isk[y] = 1.0f / sk[y];
+    const float* sqp = scale + head * c;
+    if (T == 6) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = (qt0 + x) * 16 + g * 4 + e;
+                const float isq = 1.0f / sqp[row];
+#pragma unroll
+                for (int y = 0; y < 3; ++y) out[(long)row * c + (kt0 + y) * 16 + i] = acc[x][y][e] * (isq * isk[y]);
+            }
+        if (g == 0) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                if (do_q) out[c * c + (qt0 + m) * 16 + i] = nq[m];
+                if (do_k) out[c * c + c + (kt0 + m) * 16 + i] = nk[m];
+            }
+        }
+    } else {
+        // waves 0/1 hold q tiles {0, 1} over the two pixel halves, waves 2/3 q tile 2 and the k norms:
+        // combine through LDS in wave order
+        asm volatile("s_barrier" ::: "memory");      // every wave is done reading the ring
+        float* mine = smem + wave * REC;
+#pragma unroll
+        for (int x = 0; x < NQ; ++x) {
+            if (x < nq_used) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = (qt0 + x) * 16 + g * 4 + e;
+                    const float isq = 1.0f / sqp[row];
+#pragma unroll
+                    for (int y = 0; y < 3; ++y) mine[row * c + y * 16 + i] = acc[x][y][e] * (isq * isk[y]);
+                }
+                if (g == 0) mine[c * c + (qt0 + x) * 16 + i] = nq[x];
+            }
+        }
+        if (g == 0 && do_k) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) mine[c * c + c + m * 16 + i] = nk[m];
+        }
+        __syncthreads();
+        for (int e = tid; e < REC; e += 256) {
+            const int row = e < c * c ? e / c : (e < c * c + c ? e - c * c : 32);     // k norms live with waves 2, 3
+            const int w0 = row < 32 ? 0 : 2;
+            out[e] = smem[w0 * REC + e] + smem[(w0 + 1) * REC + e];
+        }
+    }
+}
+
+template <int T>
+static int launch_gram_f16x3(const GramArgs& a, const float* scale, int B, hipStream_t stream) {
+    constexpr int NS = 3;
+    const size_t lds = (size_t)NS * 24 * 1024;
+    IRM_ALLOW_BIG_LDS((&mdta_gram_f16x3_kernel<T, NS>));
+    hipLaunchKernelGGL((mdta_gram_f16x3_kernel<T, NS>), dim3(a.heads * a.nchunk, B), dim3(256), lds, stream, a, scale);
+    return irm_launch_status();
+}
+
+extern "C" int irm_mdta_gram_f16x3_f32(const float* qkv, long bs, const float* scale, float* part, int B, int C,
+                                       int heads, int N, int chunk, hipStream_t stream) {
+    if (!qkv || !scale || !part || B <= 0 || C <= 0 || heads <= 0 || N <= 0 || chunk <= 0) return IRM_EINVAL;
+    if (C % heads || (chunk & 63) || B > 65535) return IRM_EINVAL;
+    const int c = C / heads;
+    if ((c != 48 && c != 96) || (N & 63) || (bs & 3) || !irm_aligned16(qkv)) return IRM_EINVAL;
+    if ((long)heads * ((N + chunk - 1) / chunk) > 2147483647L) return IRM_EINVAL;
+    GramArgs a{qkv, bs, part, C, heads, N, chunk, (N + chunk - 1) / chunk};
+    return c == 48 ? launch_gram_f16x3<3>(a, scale, B, stream) : launch_gram_f16x3<6>(a, scale, B, stream);
+}
+
 template <int T>
 static int launch_gram_ring(const GramArgs& a, int B, hipStream_t stream) {
     constexpr int NS = 3;
@@ -338,7 +539,13 @@ __global__ __launch_bounds__(256) void mdta_reduce_kernel(const float* __restric
     float s = 0.0f;
     if (e < rec) {
         const float* p = part + bh * nchunk * (long)rec + e;
-        for (int ch = w; ch < nchunk; ch += 4) s += p[(long)ch * rec];
+        int ch = w;
+        for (; ch + 12 < nchunk; ch += 16) {             // four loads in flight, summed in chunk order
+            const float v0 = p[(long)ch * rec], v1 = p[(long)(ch + 4) * rec], v2 = p[(long)(ch + 8) * rec],
+                        v3 = p[(long)(ch + 12) * rec];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; ch < nchunk; ch += 4) s += p[(long)ch * rec];
     }
     sm[w][threadIdx.x & 63] = s;
     __syncthreads();
@@ -407,10 +614,16 @@ __global__ __launch_bounds__(256) void mdta_finalize_kernel(FinArgs a) {
     float* mf = a.mfold + (long)b * mtiles * a.ksteps * 64;
     const int rows_per = (a.C + gridDim.z - 1) / gridDim.z;
     const int co0 = blockIdx.z * rows_per, co1 = min(co0 + rows_per, a.C);
+    // this workgroup's rows of project_out (columns of this head) into LDS: the dot products below then read LDS only
+    float* Wl = sm + c * c + 2 * c;                    // [rows_per][c]
+    for (int e = threadIdx.x; e < (co1 - co0) * c; e += 256)
+        Wl[e] = a.wout[(long)(co0 + e / c) * a.C + head * c + e % c];
+    __syncthreads();
     for (int e = co0 * c + threadIdx.x; e < co1 * c; e += 256) {
         const int co = e / c, j = e % c;
-        const float* wrow = a.wout + (long)co * a.C + head * c;
+        const float* wrow = Wl + (co - co0) * c;
         float acc = 0.0f;
+#pragma unroll 8
         for (int i = 0; i < c; ++i) acc += wrow[i] * G[i * c + j];
         const int kcol = head * c + j;
         if (a.split) {
@@ -435,7 +648,8 @@ static int mdta_finalize(const float* part, float* gsum, const float* temperatur
     if (C % heads || (long)B * heads > 65535) return IRM_EINVAL;
     const int c = C / heads;
     const int rec = c * c + 2 * c;
-    const size_t lds = (size_t)rec * sizeof(float);
+    const int zsplit = 8;
+    const size_t lds = ((size_t)rec + (size_t)((C + zsplit - 1) / zsplit) * c) * sizeof(float);
     if (lds > 64 * 1024) return IRM_EINVAL;
     hipLaunchKernelGGL(mdta_reduce_kernel, dim3((rec + 63) / 64, B * heads), dim3(256), 0, stream, part, gsum,
                        rec, nchunk);
@@ -444,7 +658,7 @@ static int mdta_finalize(const float* part, float* gsum, const float* temperatur
     // padded rows/cols of the packed matrix stay zero: the caller clears mfold once at allocation
     // (C is a multiple of 16 at every Restormer level, so normally there is no padding at all)
     FinArgs a{gsum, temperature, wout, mfold, attn, C, heads, 4 * ((C + 15) / 16), split};
-    hipLaunchKernelGGL(mdta_finalize_kernel, dim3(heads, B, 8), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(mdta_finalize_kernel, dim3(heads, B, zsplit), dim3(256), lds, stream, a);
     return irm_launch_status();
 }
 

@@ -155,11 +155,7 @@ class MambaHost(nn.Module):
         self._packed, self._packed_key, self._ws_by_stream = None, None, {}
 
     def _param_key(self):
-        ver, dev = 0, None
-        for p in self.parameters():
-            dev = p.device
-            ver += p._version + (p.data_ptr() & 0xFFFF)
-        return (str(dev), ver)
+        return _hip.param_key(self)
 
     def _buf(self, name, numel, device):
         ws = self._ws_by_stream.setdefault(torch.cuda.current_stream().cuda_stream, {})

@@ -224,17 +224,25 @@ def mdta_plan(B: int, C: int, heads: int, N: int):
     return chunk, -(-N // chunk), c * c + 2 * c
 
 
-def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, attn=None, split: bool = False):
+def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, attn=None, split: bool = False,
+              gram_scale=None):
     """Gram pass + finalize: mfold[b] <- packed(W_out @ blockdiag(softmax(...))) (restormer.py:115-131);
-    split: in the fp16 hi/lo order of the emulated GEMM kernels."""
+    split: in the fp16 hi/lo order of the emulated GEMM kernels.  gram_scale (_hip.gram_scales): the Gram pass runs
+    as an fp32 emulation on the fp16 matrix cores (c = 48 / 96 channels per head, N % 64 == 0)."""
     _chk(qkv, "qkv")
     B, _, H, W = qkv.shape
     N = H * W
     chunk, nchunk, rec = mdta_plan(B, C, heads, N)
     assert part.numel() >= B * heads * nchunk * rec and gsum.numel() >= B * heads * rec
     c = C // heads
-    _launch("mdta_gram", 2.0 * B * heads * c * c * N, 8.0 * B * C * N, "irm_mdta_gram_f32", _hip.ptr(qkv), _bs(qkv),
-            _hip.ptr(part), B, C, heads, N, chunk, tag=f"C{C} h{heads} N{N} B{B} chunk{chunk}")
+    if gram_scale is not None and c in (48, 96) and N % 64 == 0 and not os.environ.get("IRM_GRAM_EXACT"):
+        assert gram_scale.numel() == 2 * C and gram_scale.is_contiguous()
+        _launch("mdta_gram_f16x3", 2.0 * B * heads * c * c * N, 8.0 * B * C * N, "irm_mdta_gram_f16x3_f32", _hip.ptr(qkv),
+                _bs(qkv), _hip.ptr(gram_scale), _hip.ptr(part), B, C, heads, N, chunk,
+                tag=f"C{C} h{heads} N{N} B{B} chunk{chunk}")
+    else:
+        _launch("mdta_gram", 2.0 * B * heads * c * c * N, 8.0 * B * C * N, "irm_mdta_gram_f32", _hip.ptr(qkv), _bs(qkv),
+                _hip.ptr(part), B, C, heads, N, chunk, tag=f"C{C} h{heads} N{N} B{B} chunk{chunk}")
     _launch("mdta_finalize", 2.0 * B * C * C * c, 4.0 * B * (heads * nchunk * rec + C * C),
             "irm_mdta_finalize_f16x3_f32" if split else "irm_mdta_finalize_f32",
             _hip.ptr(part), _hip.ptr(gsum), _hip.ptr(temperature), _hip.ptr(wout), _hip.ptr(mfold), _hip.ptr(attn),

@@ -153,12 +153,7 @@ class Restormer(nn.Module):
         return self
 
     def _param_key(self):
-        dev = None
-        ver = 0
-        for p in self.parameters():
-            dev = p.device
-            ver += p._version + (p.data_ptr() & 0xFFFF)
-        return (str(dev), ver)
+        return _hip.param_key(self)
 
     def _pack(self):
         """Packed / flattened device copies of the weights, rebuilt when parameters change."""
@@ -198,6 +193,11 @@ class Restormer(nn.Module):
                     if _hip.split_is_safe(ff.project_out.weight):
                         pk[name]["pout_s"] = _hip.pack_gemm_weight_split(ff.project_out.weight)
                     pk[name]["mfold_split"] = _hip.split_is_safe(a.project_out.weight)
+                    # Gram pass on the fp16 matrix cores where a static bound of |q|, |k| exists (WithBias LayerNorm)
+                    gs = _hip.gram_scales(a.qkv.weight, a.qkv.bias, a.qkv_dwconv.weight, a.qkv_dwconv.bias, m.norm1.w,
+                                          m.norm1.b, m.norm1.mode == ops.LN_WITHBIAS)
+                    if gs is not None:
+                        pk[name]["gram_s"] = gs.to(a.qkv.weight.device)
                 if self._split and ops.can_fuse_gdfn(m.dim, 4):
                     # whole-branch kernels (fused_block.hip): LN + qkv + dwconv, and the complete GDFN
                     pk[name].update(
@@ -285,7 +285,8 @@ class Restormer(nn.Module):
             mfold = torch.zeros(B * mfold_n, dtype=torch.float32, device=dev)
             ws[("mfold", C, B)] = mfold
         # the folded per-image matrix in the order of the kernel that applies it (fp16 hi/lo when emulated)
-        ops.mdta_fold(qkv2, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=s_fold)
+        ops.mdta_fold(qkv2, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=s_fold,
+                      gram_scale=w.get("gram_s") if split else None)
         if fuse_dw:
             ops.dwgemm(mfold, w["v_dwp"], qkv[:, 2 * C:], x, C, C, gate=False, res=x, bias=w["wout_b"],
                        w_bs=mfold_n, stats_out=stats if fuse else None, split=s_fold)
@@ -331,7 +332,7 @@ class Restormer(nn.Module):
             mfold = torch.zeros(B * mfold_n, dtype=torch.float32, device=dev)
             ws[("mfold", C, B)] = mfold
         s_fold = w.get("mfold_split", False)
-        ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=s_fold)
+        ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=s_fold, gram_scale=w.get("gram_s"))
         ops.gemm1x1(mfold, qkv[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n, split=s_fold)
         ops.gdfn_fused(w["gdfn_f"], x, alt, C, hid, ln_mode=blk.norm2.mode, bias=w["pout_b"])
         return alt

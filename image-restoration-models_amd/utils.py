@@ -217,8 +217,8 @@ def _window_on(device, ps: int) -> torch.Tensor:
 _GRAPHS: dict = {}
 
 
-def _weights_version(model: Module) -> int:
-    return sum(p._version for p in model.parameters())
+def _weights_version(model: Module):
+    return _hip.param_key(model)
 
 
 def graphed_forward(model: Module, x: torch.Tensor) -> torch.Tensor:

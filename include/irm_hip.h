@@ -167,6 +167,16 @@ int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long x_bs, floa
 int irm_mdta_gram_f32(const float* qkv, long bs, float* part, int B, int C, int heads, int N, int chunk,
                       irm_stream_t stream);
 
+/* The same pass as an fp32 emulation on the fp16 matrix cores (three v_mfma_f32_16x16x32_f16 per product, fp32
+ * accumulation; the squared norms stay in fp32 on the vector pipe): the sweep over q, k becomes a memory stream.
+ * scale: [2C] power-of-two factors (q channels, then k channels) applied to the operands before the fp16 hi/lo split
+ * and removed again from the records (exact).  The caller guarantees |q_c| scale_c < 65504 for EVERY input - i.e.
+ * scale comes from a static bound of the producing layers (WithBias LayerNorm -> qkv conv -> depth-wise conv; host
+ * side: gram_scales); without such a bound (BiasFree LayerNorm) irm_mdta_gram_f32 is the entry point to use.
+ * c in {48, 96}, N % 64 == 0, chunk % 64 == 0, 16-byte aligned rows; same partial records as irm_mdta_gram_f32. */
+int irm_mdta_gram_f16x3_f32(const float* qkv, long bs, const float* scale, float* part, int B, int C, int heads, int N,
+                            int chunk, irm_stream_t stream);
+
 /* MDTA pass 2: reduce the partials (gsum: workspace [B][heads][c*c+2c]),
  * softmax((G_ij / (max(|q_i|,1e-12) max(|k_j|,1e-12))) * temperature[head]) and
  * fold with project_out: mfold[b] = packed(W_out * blockdiag(A_heads)), a C x C

@@ -314,6 +314,38 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert _hip.load().irm_version() == 1
 
 
+def test_asan_host_build_rejects_bad_arguments(tmp_path):
+    """`make asan` (host side under AddressSanitizer; the GPU side cannot be sanitised on this pool): every C-ABI entry
+    point called with null pointers / zero sizes must return IRM_EINVAL before touching HIP, with no ASan report.
+    Runs in a child process because the ASan runtime has to be the first library of the process (LD_PRELOAD)."""
+    import glob
+    import subprocess
+    import sys
+    rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not rt:
+        pytest.skip("no ASan runtime in this ROCm image")
+    csrc = os.path.join(os.path.dirname(_hip.LIB_PATH), "csrc")
+    lib = os.path.join(os.path.dirname(_hip.LIB_PATH), "libirm_hip_asan.so")
+    subprocess.run(["make", "-C", csrc, "asan", "-j4"], check=True, capture_output=True, timeout=900)
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from irm_amd import _hip\n"
+        "lib = C.CDLL(%r)\n"
+        "bad = []\n"
+        "for name, sig in _hip.SIGNATURES.items():\n"
+        "    if name == 'irm_version': continue\n"
+        "    f = getattr(lib, name); f.argtypes = sig; f.restype = C.c_int\n"
+        "    rc = f(*[t(0) for t in sig])\n"
+        "    if rc != -1: bad.append((name, rc))\n"
+        "print('checked', len(_hip.SIGNATURES) - 1, 'bad', bad)\n"
+        "sys.exit(1 if bad else 0)\n" % (os.path.dirname(os.path.dirname(_hip.LIB_PATH)), lib))
+    env = dict(os.environ, LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=99")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr
+
+
 def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch):
     m = restormer.Restormer()
     with pytest.raises(_hip.HipLibraryError):

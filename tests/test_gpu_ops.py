@@ -312,6 +312,44 @@ def test_mdta_fold(dev, B, C, heads, H, W):
         assert (y2 - y).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("B,C,heads,H,W,span", [(2, 48, 1, 16, 24, 1.0), (1, 96, 2, 16, 16, 1.0), (2, 96, 1, 8, 40, 1.0),
+                                                (1, 192, 4, 8, 8, 1.0), (1, 384, 8, 8, 8, 1.0), (1, 96, 1, 64, 64, 1.0),
+                                                (2, 192, 2, 32, 48, 1.0), (3, 48, 1, 48, 64, 1.0),
+                                                (1, 96, 1, 32, 32, 2.0 ** -9), (1, 48, 1, 32, 32, 0.999)])
+def test_mdta_gram_f16x3(dev, B, C, heads, H, W, span):
+    """Gram pass emulated on the fp16 matrix cores against float64 and against the f32-input MFMA pass: records
+    (Gram + squared norms) and the attention matrix.  scale = 2^14 / (a bound of |q|, |k| per channel); span = how
+    much of that bound the data uses (2^-9: typical trained activations, far below the static bound; 0.999: at it)."""
+    N, c = H * W, C // heads
+    bound = rnd(f"gb{C}{heads}", (2 * C,), 0.5, 40.0)
+    qkv = rnd(f"gq{C}{heads}{H}", (B, 3 * C, H, W))
+    qkv[:, :2 * C] *= (bound * span).view(1, 2 * C, 1, 1)
+    scale = torch.pow(2.0, torch.floor(torch.log2(2.0 ** 14.8 / bound))).float()
+    assert float((qkv[:, :2 * C].abs() * scale.view(1, -1, 1, 1)).max()) < 65504
+    temp = rnd(f"gt{C}{heads}", (heads,), 2.0, 6.0)
+    wout = rnd(f"gw{C}", (C, C), -0.3, 0.3)
+    q, k, _ = qkv.double().reshape(B, 3, heads, c, N).unbind(1)
+    G = q @ k.transpose(-1, -2)
+    attn = torch.softmax(F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-1, -2)
+                         * temp.double().view(1, heads, 1, 1), dim=-1)
+    chunk, nchunk, rec = ops.mdta_plan(B, C, heads, N)
+    qg = qkv.to(dev)
+    outs = []
+    for sc in (None, scale.to(dev)):
+        part = torch.full((B * heads * nchunk * rec,), float("nan"), device=dev)
+        gsum = torch.empty(B * heads * rec, device=dev)
+        mfold = torch.zeros(B * ops.mfold_numel(C), device=dev)
+        attn_out = torch.empty(B, heads, c, c, device=dev)
+        ops.mdta_fold(qg, part, gsum, temp.to(dev), wout.to(dev), mfold, C, heads, attn=attn_out, gram_scale=sc)
+        outs.append((gsum.cpu().double().view(B, heads, rec), attn_out.cpu().double()))
+    gref = torch.cat([G.reshape(B, heads, c * c), (q * q).sum(-1), (k * k).sum(-1)], -1)
+    mag = gref.abs().max()
+    e32, e16 = (outs[0][0] - gref).abs().max() / mag, (outs[1][0] - gref).abs().max() / mag
+    a32, a16 = (outs[0][1] - attn).abs().max(), (outs[1][1] - attn).abs().max()
+    print(f"gram C{C} h{heads} N{N} span {span:.1e}: records rel err f32 {e32:.2e} f16x3 {e16:.2e}; attn abs err f32 {a32:.2e} f16x3 {a16:.2e}")
+    assert e16 <= 2 * e32 + 2e-7 and a16 <= 2 * a32 + 2e-7
+
+
 CONV_CASES = [
     # ci, co, H, W, B, bias, relu1, res_mode, relu2, store
     (3, 48, 16, 32, 2, False, False, 0, False, 0),
