@@ -158,7 +158,10 @@ def param_key(module):
         d["_irm_plist"] = pl
         if not d.get("_irm_hooked"):
             d["_irm_hooked"] = True
-            module.register_load_state_dict_post_hook(lambda m, _keys: m.__dict__.pop("_irm_plist", None))
+
+            def _drop(m, _keys):          # (a post hook must return None)
+                m.__dict__.pop("_irm_plist", None)
+            module.register_load_state_dict_post_hook(_drop)
     if not pl:
         return (None, 0, 0)
     ver = 0
