@@ -104,7 +104,10 @@ def test_transformer_block_vs_golden(dev, golden, c, heads, h, w, ln):
 def test_transformer_block_product_path_vs_golden(dev, golden, c, heads, h, w, ln):
     """The same reference goldens through the path users and bench.py run: weights packed by Restormer._pack()
     (fp16 hi/lo splits, range guard, fused branch kernels for C <= 96) and the stage driver _run_stage."""
+    import os
     import torch.nn as nn
+    if os.environ.get("IRM_GEMM_EXACT"):
+        pytest.skip("IRM_GEMM_EXACT=1 selects the f32-MFMA entries: not the path this test is about")
     tag = f"c{c}_h{heads}_{h}x{w}_{ln}"
     host = restormer.Restormer(LayerNorm_type=ln)
     blk = restormer.restormer.TransformerBlock(c, heads, 2.66, False, ln)
