@@ -215,13 +215,25 @@ def mdta_plan(B: int, C: int, heads: int, N: int):
     """(chunk, nchunk, record size) of the Gram pass for this problem size."""
     c = C // heads
     sb = 3 if c % 48 == 0 else 2 if c % 32 == 0 else 1
-    # the LDS-DMA ring kernel (c = 48 / 96, N % 64 == 0) keeps the whole c x c Gram in one workgroup
-    nsub = 1 if (c in (48, 96) and N % 64 == 0) else (c // (16 * sb)) ** 2
-    per_wg = 1 if nsub == 1 and c in (48, 96) and N % 64 == 0 else 4        # units per workgroup
+    rec = c * c + 2 * c
+    if c in (48, 96) and N % 64 == 0 and not os.environ.get("IRM_GRAM_BLOCKS"):
+        # the LDS-DMA ring kernels keep the whole c x c Gram in one workgroup of 72 KiB LDS: 2 per CU = 512 resident.
+        # Whole rounds matter: 1026 workgroups (the old ceil(N / 1536) = 171 chunks x 6 images) are two full rounds
+        # plus a third with 2 workgroups - half a round of the chip idle.  Cost model: rounds x (chunk + a fixed
+        # per-workgroup part worth ~192 pixels: ring fill, record write-out, the reduction over one more record).
+        slots, best = 2 * 256, None
+        for chunk in range(128, 4096 + 1, 64):
+            nchunk = -(-N // chunk)
+            cost = -(-(B * heads * nchunk) // slots) * (chunk + 192)
+            if best is None or cost < best[0]:
+                best = (cost, chunk, nchunk)
+        return best[1], best[2], rec
+    nsub = (c // (16 * sb)) ** 2
     tb = int(os.environ.get("IRM_GRAM_BLOCKS", 0)) or target_blocks()
-    chunk = -(-(N * B * heads * nsub) // (per_wg * tb))
+    per_wg = 1 if (c in (48, 96) and N % 64 == 0) else 4                        # units per workgroup
+    chunk = -(-(N * B * heads * (1 if per_wg == 1 else nsub)) // (per_wg * tb))
     chunk = min(max(-(-chunk // 64) * 64, 256), 4096)
-    return chunk, -(-N // chunk), c * c + 2 * c
+    return chunk, -(-N // chunk), rec
 
 
 def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, attn=None, split: bool = False,
