@@ -146,6 +146,28 @@ def split_is_safe(w: torch.Tensor, lnw=None, lnb=None) -> bool:
     return True
 
 
+def plan_gemm(mtiles: int, blocks: int, options=(9, 8, 6, 4, 3), slots: int = 512, c0: float = 4.0):
+    """(ct, ygroups) of a 1x1-conv launch: ct output-channel tiles per pass, the passes of a pixel tile split over
+    `ygroups` workgroups.  Cost model in tile-pass units: rounds x passes per workgroup x (ct + c0), with
+    rounds = ceil(blocks x ygroups / slots) (two ring-kernel workgroups of 57-73 KiB LDS are resident per CU: 512 slots),
+    passes = ceil(ceil(mtiles / ct) / ygroups) and c0 the part of a pass that does not shrink with ct (every pass streams
+    all K input rows of its pixel tile through the LDS ring).  What it fixes: 576 workgroups on 512 slots (M 2042 / 1152,
+    K 384 at Restormer's 64 x 64 level) ran as one round plus a straggler round of 64 - nearly twice the time of 480."""
+    best = None
+    for ct in options:
+        chunks = -(-mtiles // ct)
+        for yg in range(1, chunks + 1):
+            passes = -(-chunks // yg)
+            if (yg - 1) * passes >= chunks:
+                continue                                   # an empty group
+            rounds = -(-(blocks * yg) // slots)
+            cost = rounds * passes * (ct + c0)
+            key = (cost, yg, -ct)
+            if best is None or key < best[0]:
+                best = (key, ct, yg)
+    return best[1], best[2]
+
+
 def param_key(module):
     """Cheap per-forward fingerprint of a module's weights: the parameter tuple is cached on the module, the walk reads
     only `p._version` (in-place updates, load_state_dict) plus the device and storage address of the first and last

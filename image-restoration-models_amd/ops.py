@@ -109,8 +109,12 @@ def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, 
     if res is not None:
         _chk(res, "res")
     mt = (M + 15) // 16
+    if ct is None and ygroups is None and stats_out is None:
+        # pixels per workgroup of the kernel that will run: 256 (emulated, no residual) or 128
+        bn = 256 if (split and res is None) else 128
+        ct, ygroups = _hip.plan_gemm(mt, -(-N // bn) * B)
     if ct is None:
-        ct = _hip.choose_ct(mt, blocks=(-(-N // 128) * B) if stats_out is None else 1 << 30)
+        ct = _hip.choose_ct(mt)
     if ygroups is None:
         nchunks = -(-mt // ct)
         blocks = -(-N // 128) * B
