@@ -351,8 +351,9 @@ def main():
                             "--no-legs", "--streams", "2"], {})
             out["value_two_streams"] = None if ts is None else ts["value"]
             out["value_two_streams_note"] = ("model.num_streams = 2: the frame's tiles run as two groups on two HIP streams, so "
-                                             "the tails of ~600 launches overlap; same results.  Not `value`: per-launch events "
-                                             "of overlapping kernels are not kernel durations, so the roofline leg stays on one stream")
+                                             "the tails of ~600 launches overlap.  Not `value`: per-launch events of overlapping kernels "
+                                             "are not kernel durations, and overlapping forwards are not bit-reproducible run to run "
+                                             "(+-1 in <0.2 % of the output bytes; DESIGN section 6)")
             pc = child_leg(["--leg", "pcie", "--steps", "8", "--warmup", "2"], {})
             out["value_pcie_inclusive"] = None if pc is None else pc["value"]
             out["value_pcie_inclusive_note"] = ("get_model_prediction(model, numpy_frame, device, **patch_config): uint8 frame in "
