@@ -555,6 +555,8 @@ __global__ __launch_bounds__(256) void mdta_reduce_kernel(const float* __restric
     }
 }
 
+__device__ __forceinline__ bool irm_aligned16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // finalize: one workgroup per (batch, head).
 //  1. one thread per row: logits, max, exp, sum -> A row in LDS;
 //  2. Mfold[co][head*c + j] = sum_i Wout[co][head*c + i] * A[i][j], stored packed:
@@ -569,7 +571,10 @@ struct FinArgs {
     int split;                  // mfold in irm_gemm1x1_f16x3_f32's fp16 hi/lo order instead of packed fp32
 };
 
-__global__ __launch_bounds__(256) void mdta_finalize_kernel(FinArgs a) {
+// 16 waves: the softmax rows are chains of dependent cross-lane reductions (latency, not throughput), 6 rows per wave
+// instead of 24
+__global__ __launch_bounds__(1024) void mdta_finalize_kernel(FinArgs a) {
+    constexpr int NT = 1024;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int c = a.C / a.heads;
     const int head = blockIdx.x, b = blockIdx.y;
@@ -578,16 +583,36 @@ __global__ __launch_bounds__(256) void mdta_finalize_kernel(FinArgs a) {
     float* G = sm;                 // [c][c], overwritten by A
     float* nrm = sm + c * c;       // [2c] squared norms of q rows, k rows
     const float* p = a.gsum + ((long)b * a.heads + head) * rec;
-    for (int e = threadIdx.x; e < rec; e += 256) sm[e] = p[e];
+    if ((rec & 3) == 0 && rec <= 4 * NT * 3 && irm_aligned16_dev(p)) {
+        // all loads of a thread in flight at once (a plain copy loop is 37 dependent round trips at c = 96)
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        const int n4 = rec >> 2;
+        float4 v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int e = threadIdx.x + NT * k;
+            v[k] = e < n4 ? p4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int e = threadIdx.x + NT * k;
+            if (e < n4) reinterpret_cast<float4*>(sm)[e] = v[k];
+        }
+    } else {
+        for (int e = threadIdx.x; e < rec; e += NT) sm[e] = p[e];
+    }
+    __syncthreads();
+    // squared norms -> 1 / max(|q_i|, 1e-12), 1 / max(|k_j|, 1e-12) once (F.normalize's eps), instead of a square root
+    // and a division per logit
+    for (int e = threadIdx.x; e < 2 * c; e += NT) nrm[e] = 1.0f / fmaxf(sqrtf(nrm[e]), 1e-12f);
     __syncthreads();
     const float temp = a.temperature[head];
     // softmax: one wave per row, lanes over the columns
-    for (int i = wave; i < c; i += 4) {
-        const float qi = fmaxf(sqrtf(nrm[i]), 1e-12f);
+    for (int i = wave; i < c; i += NT / 64) {
+        const float qi = nrm[i] * temp;
         float m = -INFINITY;
         for (int j = lane; j < c; j += 64) {
-            const float kj = fmaxf(sqrtf(nrm[c + j]), 1e-12f);
-            const float l = G[i * c + j] / (qi * kj) * temp;
+            const float l = G[i * c + j] * (qi * nrm[c + j]);
             G[i * c + j] = l;
             m = fmaxf(m, l);
         }
@@ -607,7 +632,7 @@ __global__ __launch_bounds__(256) void mdta_finalize_kernel(FinArgs a) {
     __syncthreads();
     if (a.attn && blockIdx.z == 0) {
         float* o = a.attn + ((long)b * a.heads + head) * c * c;
-        for (int e = threadIdx.x; e < c * c; e += 256) o[e] = G[e];
+        for (int e = threadIdx.x; e < c * c; e += NT) o[e] = G[e];
     }
     // fold with project_out; the output rows are split over gridDim.z workgroups
     const int mtiles = (a.C + 15) / 16;
@@ -616,10 +641,10 @@ __global__ __launch_bounds__(256) void mdta_finalize_kernel(FinArgs a) {
     const int co0 = blockIdx.z * rows_per, co1 = min(co0 + rows_per, a.C);
     // this workgroup's rows of project_out (columns of this head) into LDS: the dot products below then read LDS only
     float* Wl = sm + c * c + 2 * c;                    // [rows_per][c]
-    for (int e = threadIdx.x; e < (co1 - co0) * c; e += 256)
+    for (int e = threadIdx.x; e < (co1 - co0) * c; e += NT)
         Wl[e] = a.wout[(long)(co0 + e / c) * a.C + head * c + e % c];
     __syncthreads();
-    for (int e = co0 * c + threadIdx.x; e < co1 * c; e += 256) {
+    for (int e = co0 * c + threadIdx.x; e < co1 * c; e += NT) {
         const int co = e / c, j = e % c;
         const float* wrow = Wl + (co - co0) * c;
         float acc = 0.0f;
@@ -658,7 +683,7 @@ static int mdta_finalize(const float* part, float* gsum, const float* temperatur
     // padded rows/cols of the packed matrix stay zero: the caller clears mfold once at allocation
     // (C is a multiple of 16 at every Restormer level, so normally there is no padding at all)
     FinArgs a{gsum, temperature, wout, mfold, attn, C, heads, 4 * ((C + 15) / 16), split};
-    hipLaunchKernelGGL(mdta_finalize_kernel, dim3(heads, B, zsplit), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(mdta_finalize_kernel, dim3(heads, B, zsplit), dim3(1024), lds, stream, a);
     return irm_launch_status();
 }
 
