@@ -466,3 +466,83 @@ def test_conv3x3_f16x3(dev, ci, co, H, W, B, bias, relu1, res_mode, relu2, store
     print(f"conv3x3 f16x3 {tag}: {e16:.3e} (exact f32 kernel {e32:.3e})")
     assert e16 <= TOL * scale and e16 <= 2.0 * e32 + 4e-7 * scale
     assert torch.all(y16[:, oc] == 7.0)
+
+
+# --------------------------------------------------------------------------- no writes outside the output
+def _guarded(dev, shape, pad=1 << 14):
+    n = int(np.prod(shape))
+    buf = torch.full((n + 2 * pad,), 12345.0, device=dev)
+    return buf, buf[pad:pad + n].view(*shape), pad
+
+
+def _intact(buf, n, pad):
+    return bool((buf[:pad] == 12345.0).all()) and bool((buf[pad + n:] == 12345.0).all())
+
+
+@pytest.mark.parametrize("C,H,W", [(48, 64, 96), (96, 40, 56), (192, 32, 32), (384, 16, 24), (96, 9, 15)])
+def test_no_write_outside_the_output(dev, C, H, W):
+    """Every kernel of a TransformerBlock and the dense convs write into the middle of a sentinel-filled buffer: the
+    sentinels on both sides must survive (tile / chunk tails, masked lanes, pixel-shuffle stores, odd sizes)."""
+    B = 2
+    hid = int(C * 2.66)
+    X = rnd(f"cx{C}{H}", (B, C, H, W)).to(dev)
+    checks = []
+
+    def run(name, shape, fn):
+        buf, y, pad = _guarded(dev, shape)
+        fn(y)
+        torch.cuda.synchronize()
+        checks.append((name, _intact(buf, y.numel(), pad)))
+    aligned = W % 4 == 0
+    run("ln_stats", (B, 2, H, W), lambda y: ops.ln_stats(X, y))
+    st = torch.empty(B, 2, H, W, device=dev)
+    ops.ln_stats(X, st)
+    lnw, lnb = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    for M in (3 * C, 2 * hid):
+        for split in ((True, False) if aligned else (False,)):
+            w = rnd(f"cw{M}{C}", (M, C), -0.2, 0.2)
+            wp = (_hip.pack_gemm_weight_split(w) if split else _hip.pack_gemm_weight(w)).to(dev)
+            run(f"gemm LN M{M} split{int(split)}", (B, M, H, W),
+                lambda y: ops.gemm1x1(wp, X, y, M, C, stats=st, lnw=lnw, lnb=lnb, ln_mode=1, split=split))
+    G = rnd(f"cg{C}{H}", (B, hid, H, W)).to(dev)
+    for split in ((True, False) if aligned else (False,)):
+        w = rnd(f"cp{C}", (C, hid), -0.2, 0.2)
+        wp = (_hip.pack_gemm_weight_split(w) if split else _hip.pack_gemm_weight(w)).to(dev)
+
+        def inplace(y):
+            y.copy_(X)
+            ops.gemm1x1(wp, G, y, C, hid, res=y, split=split)
+        run(f"gemm res in place split{int(split)}", (B, C, H, W), inplace)
+    Hh = rnd(f"ch{C}{H}", (B, 2 * hid, H, W)).to(dev)
+    run("dwconv3x3_gate", (B, hid, H, W), lambda y: ops.dwconv3x3_gate(Hh, rnd(f"cdg{C}", (2 * hid, 9), -0.4, 0.4).to(dev), y))
+    QKV = rnd(f"cq{C}{H}", (B, 3 * C, H, W)).to(dev)
+    run("dwconv3x3", (B, 3 * C, H, W), lambda y: ops.dwconv3x3(QKV, rnd(f"cd{C}", (3 * C, 9), -0.4, 0.4).to(dev), y))
+    heads = max(1, C // 48)
+    temp, wout = torch.ones(heads, device=dev), rnd(f"co{C}", (C, C), -0.3, 0.3).to(dev)
+    chunk, nchunk, rec = ops.mdta_plan(B, C, heads, H * W)
+    sc = torch.full((2 * C,), 1024.0, device=dev)
+    for gs in (None, sc):
+        bp, part, p1 = _guarded(dev, (B * heads * nchunk * rec,))
+        bg, gsum, p2 = _guarded(dev, (B * heads * rec,))
+        bm, mf, p3 = _guarded(dev, (B * ops.mfold_numel(C),))
+        mf.zero_()
+        ops.mdta_fold(QKV, part, gsum, temp, wout, mf, C, heads, split=aligned, gram_scale=gs)
+        torch.cuda.synchronize()
+        checks.append((f"mdta f16x3={gs is not None}", _intact(bp, part.numel(), p1) and _intact(bg, gsum.numel(), p2)
+                       and _intact(bm, mf.numel(), p3)))
+    if C <= 96 and aligned:
+        pk = _hip.pack_gdfn_fused(rnd("fa", (2 * hid, C), -.3, .3).to(dev), None, rnd("fb", (2 * hid, 9), -.4, .4), None,
+                                  rnd("fc", (C, hid), -.3, .3), rnd("fd", (C,), .5, 1.5), rnd("fe", (C,), -.2, .2))
+        run("gdfn_fused", (B, C, H, W), lambda y: ops.gdfn_fused(pk, X, y, C, hid, ln_mode=1))
+        pkq = _hip.pack_qkv_fused(rnd("fq", (3 * C, C), -.3, .3).to(dev), None, rnd("fr", (3 * C, 9), -.4, .4), None,
+                                  rnd("fd", (C,), .5, 1.5), rnd("fe", (C,), -.2, .2))
+        run("qkv_dw_fused", (B, 3 * C, H, W), lambda y: ops.qkv_dw_fused(pkq, X, y, C, 3 * C, ln_mode=1))
+    if H % 2 == 0 and W % 2 == 0:
+        for co, mode in ((C // 2, 1), (2 * C, 2), (C, 0)):
+            wc = rnd(f"cc{C}{co}", (co, C, 3, 3), -0.05, 0.05).to(dev)
+            oc, oh, ow = (co * 4, H // 2, W // 2) if mode == 1 else (co // 4, H * 2, W * 2) if mode == 2 else (co, H, W)
+            for cw in (_hip.pack_conv3x3(wc), _hip.pack_conv3x3_weight(wc).to(dev)):
+                run(f"conv3x3 co{co} mode{mode} {'emulated' if not torch.is_tensor(cw) else 'exact'}", (B, oc, oh, ow),
+                    lambda y: ops.conv3x3(cw, X, y, C, co, store_mode=mode))
+    bad = [n for n, ok in checks if not ok]
+    assert not bad, f"writes outside the output: {bad}"
