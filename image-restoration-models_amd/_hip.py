@@ -25,6 +25,8 @@ SIGNATURES = {
     "irm_ln_stats_f32": [_P, _L, _P, _I, _I, _I, _F, _P],
     "irm_gemm1x1_f32": [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P],
     "irm_gemm1x1_f16x3_f32": [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P],
+    "irm_ln_split_f16": [_P, _L, _P, _P, _I, _F, _F, _P, _I, _I, _I, _P],
+    "irm_gemm_presplit_f16x3_f32": [_P, _P, _P, _L, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "irm_dwconv3x3_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
     "irm_dwconv3x3_gate_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "irm_dwgemm_f32": [_P, _L, _P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _F, _P],
@@ -144,6 +146,80 @@ def split_is_safe(w: torch.Tensor, lnw=None, lnb=None) -> bool:
         if not (bound < 2.0 ** 15):
             return False
     return True
+
+
+def _pow2_floor(v: float) -> float:
+    import math
+    return 2.0 ** math.floor(math.log2(v))
+
+
+def pack_gemm_weight_presplit(w: torch.Tensor):
+    """W [M][K] (K % 32 == 0) -> (fragments, s_w) for irm_gemm_presplit_f16x3_f32: W s_w split into fp16 hi + lo with the
+    power of two s_w chosen so that max|W| s_w lies in [2^13, 2^14) (the lo parts stay normal fp16 numbers for weights
+    of any magnitude), in MFMA fragment order [mtile][k-step][hi|lo][lane = 16 g + m][e] = part[16 mtile + m][32 ks + 8 g + e]
+    (rows beyond M zero).  Returned as a float32 view (two halves per element)."""
+    w = w.detach().reshape(w.shape[0], -1).float()
+    m, k = w.shape
+    assert k % 32 == 0
+    mt, ks = (m + 15) // 16, k // 32
+    amax = float(w.abs().max()) if w.numel() else 0.0
+    s_w = _pow2_floor(2.0 ** 14 / amax) if amax > 0 and amax == amax else 1.0
+    if amax * s_w >= 2.0 ** 14:
+        s_w *= 0.5
+    wpad = torch.zeros(mt * 16, k, dtype=torch.float32, device=w.device)
+    wpad[:m] = w * s_w
+    hi = wpad.half()
+    lo = (wpad - hi.float()).half()
+
+    def arrange(t):                                   # [mt][16 m][ks][4 g][8 e] -> [mt][ks][g][m][e]
+        return t.view(mt, 16, ks, 4, 8).permute(0, 2, 3, 1, 4)
+    packed = torch.stack([arrange(hi), arrange(lo)], dim=2).contiguous()      # [mt][ks][2][g][m][e]
+    return packed.view(-1).view(torch.float32), s_w
+
+
+def ln_split_scale(lnw: torch.Tensor, lnb, K: int, with_bias: bool) -> float:
+    """Power-of-two operand scale s_x of irm_ln_split_f16.  A WithBias LayerNorm output obeys |y_j| <= sqrt(K - 1) |w_j|
+    + |b_j| for ANY input: s_x puts that bound just below 2^15, overflow is impossible.  A BiasFree LayerNorm
+    (x / sqrt(var + eps) * w: the mean is not removed) has no such bound; s_x leaves 16x headroom over sqrt(K) max|w|
+    and the kernel clamps at +-65000 (a lower scale costs nothing for ordinary values: lo parts stay normal fp16 down
+    to |y| s_x = 2^-3)."""
+    wmax = float(lnw.detach().abs().max())
+    bmax = float(lnb.detach().abs().max()) if (with_bias and lnb is not None) else 0.0
+    bound = wmax * (max(K - 1, 1) ** 0.5) + bmax
+    if not (bound > 0.0) or bound != bound:
+        return 1.0
+    s = _pow2_floor(2.0 ** 15 / bound)
+    if bound * s >= 2.0 ** 15:
+        s *= 0.5
+    return s if with_bias else s / 16.0
+
+
+def plan_presplit(mtiles: int, npt: int, K: int, c0: float | None = None):
+    """(ct, mgroups, wg_shape) of an irm_gemm_presplit_f16x3_f32 launch: ct output tiles per chunk, the chunks of a pixel
+    block split over `mgroups` workgroups.  K 192: four waves x three pixel tiles, ct 4, two workgroups per CU (512
+    slots; measured best of 42 / 32 / 43 on 6 x 128^2: 128 vs 145 us for M 1020); K 384: eight waves x one tile, one
+    workgroup per CU.  cost = rounds of the slots x (chunks per workgroup x ct + c0), c0 = the part that does not shrink
+    with the tile range (loading the resident operands)."""
+    if K == 192:
+        shape, per_wg, slots, cts = 43, 12, 512, (4,)
+    else:
+        shape, per_wg, slots, cts = 81, 8, 256, (8, 6)
+    if c0 is None:
+        c0 = 8.0 if K == 192 else 6.0      # (a workgroup's 24 KiB of resident operands per wave cost about that many tile-stages)
+    nblk = -(-npt // per_wg)
+    best = None
+    for ct in cts:
+        chunks = -(-mtiles // ct)
+        for mg in range(1, chunks + 1):
+            cpg = -(-chunks // mg)
+            if (mg - 1) * cpg >= chunks:
+                continue                                   # an empty group
+            rounds = -(-(nblk * mg) // slots)
+            cost = rounds * (cpg * ct + c0)
+            key = (cost, mg, -ct)
+            if best is None or key < best[0]:
+                best = (key, ct, mg)
+    return best[1], best[2], shape
 
 
 def plan_gemm(mtiles: int, blocks: int, options=(9, 8, 6, 4, 3), slots: int = 512, c0: float = 4.0):

@@ -74,11 +74,20 @@ struct BlendArgs {
     float post_scale, post_shift;   // postprocess v*scale+shift (DeblurGANv2 (x+1)/2); 1,0 = off
 };
 
+// One workgroup blends BLEND_PER_WG consecutive output elements (256 threads x 8 rounds) and adds its squared error
+// with ONE integer atomic: a frame of 1280x720x3 bytes takes 1 350 atomics on the single accumulator instead of one
+// per wave (43 200 same-address atomics serialised at the L2: 0.5 ms of a 57 ms frame).  Integer sums: order independent.
+#define BLEND_PER_WG 2048
+
 __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a) {
     const long total = (long)a.H * a.W * a.Co;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     unsigned long long err = 0;
-    if (idx < total) {
+    const bool albu = a.post_scale != 1.0f || a.post_shift != 0.0f;
+    const float peak = a.is_u16 ? 65535.0f : 255.0f;
+#pragma unroll 1
+    for (int round = 0; round < BLEND_PER_WG / 256; ++round) {
+        const long idx = (long)blockIdx.x * BLEND_PER_WG + round * 256 + threadIdx.x;
+        if (idx >= total) break;
         const int c = (int)(idx % a.Co);
         const long t = idx / a.Co;
         const int x = (int)(t % a.W), y = (int)(t / a.W);
@@ -87,13 +96,12 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a) {
             const int ly = y - a.origins[2 * i], lx = x - a.origins[2 * i + 1];
             if (ly < 0 || ly >= a.th || lx < 0 || lx >= a.tw) continue;
             float p = a.pred[(((long)i * a.Cp + c) * a.ph + ly) * a.pw + lx];
-            if (a.post_scale != 1.0f || a.post_shift != 0.0f) p = __fmul_rn(__fadd_rn(p, a.post_shift), a.post_scale);
+            if (albu) p = __fmul_rn(__fadd_rn(p, a.post_shift), a.post_scale);
             const float w = a.window[ly * a.ps + lx];
             acc = __fadd_rn(acc, __fmul_rn(p, w));          // utils.py:433
             wsum = __fadd_rn(wsum, w);                       // utils.py:434
         }
         float v = __fdiv_rn(acc, fmaxf(wsum, 1e-8f));        // utils.py:440
-        const float peak = a.is_u16 ? 65535.0f : 255.0f;
         v = rintf(fminf(fmaxf(__fmul_rn(v, peak), 0.0f), peak));   // clip, round half to even
         const unsigned q = (unsigned)v;
         if (a.is_u16) reinterpret_cast<unsigned short*>(a.out)[idx] = (unsigned short)q;
@@ -102,14 +110,20 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a) {
             const int tv = a.is_u16 ? reinterpret_cast<const unsigned short*>(a.target)[idx]
                                     : reinterpret_cast<const unsigned char*>(a.target)[idx];
             const long d = (long)q - tv;
-            err = (unsigned long long)(d * d);
+            err += (unsigned long long)(d * d);
         }
     }
     if (a.target && a.sse) {
-        // wave reduction then one integer atomic per wave
+        // wave reduction, the four waves meet in LDS, one integer atomic per workgroup
+        __shared__ unsigned long long part[4];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) err += __shfl_xor(err, o);
-        if ((threadIdx.x & 63) == 0 && err) atomicAdd(a.sse, err);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = err;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long s = part[0] + part[1] + part[2] + part[3];
+            if (s) atomicAdd(a.sse, s);
+        }
     }
 }
 
@@ -122,6 +136,6 @@ extern "C" int irm_window_blend(const float* pred, const int* origins, const flo
     BlendArgs a{pred, origins, window, out, target, sse, H, W, Co, Cp, th, tw, ph, pw, ps, T, is_u16,
                 post_scale, post_shift};
     const long total = (long)H * W * Co;
-    hipLaunchKernelGGL(blend_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(blend_kernel, dim3((unsigned)((total + BLEND_PER_WG - 1) / BLEND_PER_WG)), dim3(256), 0, stream, a);
     return irm_launch_status();
 }

@@ -138,6 +138,36 @@ def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, 
             _hip.ptr(res_scale), tag=f"M{M} K{K} N{N} B{B} ln{int(ln_mode)} res{int(res is not None)} ct{ct} yg{ygroups}")
 
 
+def can_presplit(K: int, N: int) -> bool:
+    """Shapes of the pre-split LayerNorm + 1x1 conv path (gemm_ps.hip): the C >= 192 levels of Restormer."""
+    return K in (192, 384) and N % 16 == 0
+
+
+def ln_split(x: torch.Tensor, xs: torch.Tensor, lnw, lnb, ln_mode: int, scale: float, eps: float = 1e-5):
+    """xs = fp16 hi/lo fragments of LN(x) * scale (irm_ln_split_f16); xs: flat float32 buffer of B*K*N elements."""
+    _chk(x, "x")
+    B, K, H, W = x.shape
+    N = H * W
+    assert xs.numel() >= B * K * N and xs.is_contiguous() and xs.dtype == torch.float32
+    _launch("ln_split", 8.0 * B * K * N, 8.0 * B * K * N, "irm_ln_split_f16", _hip.ptr(x), _bs(x), _hip.ptr(lnw),
+            _hip.ptr(lnb), int(ln_mode), float(scale), float(eps), _hip.ptr(xs), B, K, N, tag=f"K{K} N{N} B{B}")
+
+
+def gemm_presplit(wps: torch.Tensor, xs: torch.Tensor, y: torch.Tensor, M: int, K: int, *, out_scale: float, bias=None,
+                  ct: int | None = None, mgroups: int | None = None, wg_shape: int = 0):
+    """y = (W xs) * out_scale + bias with xs from ln_split and wps from _hip.pack_gemm_weight_presplit
+    (out_scale = 1 / (s_w s_x))."""
+    _chk(y, "y")
+    B, _, H, W = y.shape
+    N = H * W
+    assert y.shape[1] >= M and can_presplit(K, N) and xs.numel() >= B * K * N
+    if ct is None or mgroups is None:
+        ct, mgroups, wg_shape = _hip.plan_presplit((M + 15) // 16, B * N // 16, K)
+    _launch("gemm_ps_f16x3", 2.0 * B * M * K * N, 4.0 * B * N * (K + M), "irm_gemm_presplit_f16x3_f32", _hip.ptr(wps),
+            _hip.ptr(xs), _hip.ptr(y), _bs(y), _hip.ptr(bias), float(out_scale), int(ACT_NONE), B, M, K, N, int(ct),
+            int(mgroups), int(wg_shape), tag=f"M{M} K{K} N{N} B{B} ct{ct} mg{mgroups}")
+
+
 def dwconv3x3(x, w9, y, *, bias=None, act=ACT_NONE):
     """Depth-wise 3x3 (+bias, +activation); w9: [C, 9]."""
     _chk(x, "x"), _chk(y, "y")

@@ -193,6 +193,13 @@ class Restormer(nn.Module):
                     if _hip.split_is_safe(ff.project_out.weight):
                         pk[name]["pout_s"] = _hip.pack_gemm_weight_split(ff.project_out.weight)
                     pk[name]["mfold_split"] = _hip.split_is_safe(a.project_out.weight)
+                    if m.dim in (192, 384):
+                        # LayerNorm + qkv / project_in with pre-split operands (gemm_ps.hip): (fragments, 1 / (s_w s_x), s_x);
+                        # power-of-two scales on both operands - no range guard needed
+                        for slot, conv, nrm in (("qkv_ps", a.qkv, m.norm1), ("pin_ps", ff.project_in, m.norm2)):
+                            frag, s_w = _hip.pack_gemm_weight_presplit(conv.weight)
+                            s_x = _hip.ln_split_scale(nrm.w, nrm.b, m.dim, nrm.mode == ops.LN_WITHBIAS)
+                            pk[name][slot] = (frag, 1.0 / (s_w * s_x), s_x)
                     # Gram pass on the fp16 matrix cores where a static bound of |q|, |k| exists (WithBias LayerNorm)
                     gs = _hip.gram_scales(a.qkv.weight, a.qkv.bias, a.qkv_dwconv.weight, a.qkv_dwconv.bias, m.norm1.w,
                                           m.norm1.b, m.norm1.mode == ops.LN_WITHBIAS)
@@ -261,13 +268,21 @@ class Restormer(nn.Module):
         qkv = big_a[:B * 3 * C * N].view(B, 3 * C, H, W)
         qkv2 = big_b[:B * 3 * C * N].view(B, 3 * C, H, W)
         # --- attention branch: x += project_out(softmax(q k^T) v)   (restormer.py:111-132, 147)
-        if not have_stats:
-            ops.ln_stats(x, stats)
         split = self._split and N % 4 == 0            # the emulation kernel needs the 16-byte fast path
         s_qkv, s_pin, s_pout = split and "qkv_s" in w, split and "pin_s" in w, split and "pout_s" in w
         s_fold = split and w.get("mfold_split", False)
-        ops.gemm1x1(w["qkv_s" if s_qkv else "qkv"], x, qkv, 3 * C, C, bias=w["qkv_b"], stats=stats, lnw=w["n1w"],
-                    lnb=w["n1b"], ln_mode=blk.norm1.mode, split=s_qkv)
+        presplit = split and "qkv_ps" in w and ops.can_presplit(C, N) and not os.environ.get("IRM_NO_PRESPLIT")
+        if presplit:
+            # LayerNorm + fp16 hi/lo split once (statistics in the kernel), then a pure matrix-core GEMM
+            xs = self._buf("xsplit", B * C * N, dev)
+            frag, out_scale, s_x = w["qkv_ps"]
+            ops.ln_split(x, xs, w["n1w"], w["n1b"], blk.norm1.mode, s_x)
+            ops.gemm_presplit(frag, xs, qkv, 3 * C, C, out_scale=out_scale, bias=w["qkv_b"])
+        else:
+            if not have_stats:
+                ops.ln_stats(x, stats)
+            ops.gemm1x1(w["qkv_s" if s_qkv else "qkv"], x, qkv, 3 * C, C, bias=w["qkv_b"], stats=stats, lnw=w["n1w"],
+                        lnb=w["n1b"], ln_mode=blk.norm1.mode, split=s_qkv)
         fuse_dw = "v_dwp" in w and ops.can_fuse_dw(C, W) and not os.environ.get("IRM_NO_FUSE_DW")
         if fuse_dw:
             # q, k only: the depth-wise conv of v happens inside the apply GEMM below
@@ -296,10 +311,15 @@ class Restormer(nn.Module):
         # --- feed-forward branch: x += project_out(gelu(dw(h1)) * dw(h2))   (restormer.py:88-93, 148)
         h = big_a[:B * 2 * hid * N].view(B, 2 * hid, H, W)
         g = big_b[:B * hid * N].view(B, hid, H, W)
-        if not fuse:
-            ops.ln_stats(x, stats)
-        ops.gemm1x1(w["pin_s" if s_pin else "pin"], x, h, 2 * hid, C, bias=w["pin_b"], stats=stats, lnw=w["n2w"],
-                    lnb=w["n2b"], ln_mode=blk.norm2.mode, split=s_pin)
+        if presplit:
+            frag, out_scale, s_x = w["pin_ps"]
+            ops.ln_split(x, xs, w["n2w"], w["n2b"], blk.norm2.mode, s_x)
+            ops.gemm_presplit(frag, xs, h, 2 * hid, C, out_scale=out_scale, bias=w["pin_b"])
+        else:
+            if not fuse:
+                ops.ln_stats(x, stats)
+            ops.gemm1x1(w["pin_s" if s_pin else "pin"], x, h, 2 * hid, C, bias=w["pin_b"], stats=stats, lnw=w["n2w"],
+                        lnb=w["n2b"], ln_mode=blk.norm2.mode, split=s_pin)
         emit = fuse and want_stats
         if fuse_dw:
             ops.dwgemm(w["pout_s" if s_pout else "pout"], w["ffn_dwp"], h, x, C, hid, gate=True, res=x,

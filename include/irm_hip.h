@@ -93,6 +93,28 @@ int irm_gemm1x1_f16x3_f32(const float* wp_split, long w_bs, const float* x, long
                           int ln_mode, int act, int B, int M, int K, int N, int ct, int ygroups, float* stats_out,
                           float eps, const float* res_scale, irm_stream_t stream);
 
+/* LayerNorm + 1x1 conv with PRE-SPLIT fp16 operands (gemm_ps.hip) - the C >= 192 levels of Restormer: LayerNorm
+ * (restormer.py:25-70) + Attention.qkv / FeedForward.project_in (restormer.py:82,105), K in {192, 384}.
+ *
+ * irm_ln_split_f16: xs = fp16 hi + lo of LN(x) * scale in MFMA fragment order (statistics computed in the kernel,
+ *   two passes in registers; biased variance, eps inside the root):
+ *     xs [B * N / 16][K / 32][hi | lo][64 lanes][8 halves], lane = 16 g + i: pixel 16 tile + i, channel 32 ks + 8 g + e
+ *   (2 + 2 bytes per element: the size of the fp32 tensor).  scale: a power of two that keeps LN(x) * scale inside
+ *   fp16 (host: ln_split_scale - from the static bound sqrt(K - 1) |w| + |b| of a WithBias LayerNorm; values are
+ *   clamped at +-65000).  ln_mode 1 = WithBias, 2 = BiasFree.  N % 16 == 0, K % 32 == 0, K <= 384.
+ * irm_gemm_presplit_f16x3_f32: y[b][m][n] = out_scale * sum_k W'[m][k] xs[b][k][n] + bias[m] with three
+ *   v_mfma_f32_16x16x32_f16 per product (lo*hi, hi*lo, hi*hi), fp32 accumulate; out_scale = 1 / (s_w scale).
+ *   wps [ceil(M/16)][K / 32][hi | lo][64 lanes][8 halves]: W s_w split by the host in the same fragment order (lane =
+ *   16 g + m: output channel 16 tile + m), s_w a power of two with max|W| s_w in [2^13, 2^14).
+ *   ct output tiles per pass; mgroups: workgroups sharing the output tiles of a pixel block (no empty group);
+ *   wg_shape = 10 x waves per workgroup + pixel tiles per wave: K 192: 42 or 32 (ct 6 / 8), 43 (ct 4); K 384: 81
+ *   (ct 6 / 8); 0 = default.  N % 16 == 0 (pixel tiles are numbered through the batch); act must be 0. */
+int irm_ln_split_f16(const float* x, long x_bs, const float* lnw, const float* lnb, int ln_mode, float scale, float eps,
+                     void* xs, int B, int K, int N, irm_stream_t stream);
+int irm_gemm_presplit_f16x3_f32(const void* wps, const void* xs, float* y, long y_bs, const float* bias, float out_scale,
+                                int act, int B, int M, int K, int N, int ct, int mgroups, int wg_shape,
+                                irm_stream_t stream);
+
 /* Depth-wise 3x3 convolution, zero pad 1: y[b][c] = act(dw3x3(x[b][c]; w[c]) + bias[c]).
  * Replaces Attention.qkv_dwconv (restormer.py:106) and MaIR's conv2d+SiLU.
  * w: [C][9] (device), bias: [C] or NULL. */

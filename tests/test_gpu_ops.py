@@ -211,6 +211,125 @@ def test_gemm1x1_f16x3(dev, M, K, H, W, B, ln, bias, ct):
     assert e16 < 2e-5 and e16 < 8 * max(e32, 1e-7)
 
 
+def _ln_ref(xd, lnw, lnb, ln):
+    K = xd.shape[1]
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    xn = ((xd - mu) if ln == 1 else xd) / torch.sqrt(var + 1e-5) * lnw.double().view(1, K, 1, 1)
+    return xn + lnb.double().view(1, K, 1, 1) if ln == 1 else xn
+
+
+def _unpack_presplit(frag, M, K):
+    """fp64 value of the hi + lo fragments written by the host packer / irm_ln_split_f16: [rows][K]."""
+    h = frag.view(torch.float16).double().view(-1, K // 32, 2, 4, 16, 8)      # [tile][ks][hi|lo][g][m][e]
+    v = (h[:, :, 0] + h[:, :, 1]).permute(0, 3, 1, 2, 4).reshape(-1, K)        # [tile][m][ks][g][e]
+    return v[:M]
+
+
+@pytest.mark.parametrize("K,H,W,B,ln,amp", [(192, 16, 16, 2, 1, 1.0), (192, 16, 32, 1, 2, 1.0), (384, 8, 16, 3, 1, 1.0),
+                                            (384, 16, 8, 1, 2, 1e-4), (192, 16, 16, 1, 1, 3e4)])
+def test_ln_split(dev, K, H, W, B, ln, amp):
+    """irm_ln_split_f16: hi + lo of LayerNorm(x) * s_x in fragment order against float64, from a channel slice of a
+    larger buffer; LayerNorm gains up to 30 (the static scale keeps every value inside fp16)."""
+    N = H * W
+    big = rnd(f"lsx{K}{H}{ln}", (B, K + 3, H, W), -2, 3) * amp
+    lnw = rnd(f"lsw{K}{ln}", (K,), 0.05, 30.0)
+    lnb = rnd(f"lsb{K}{ln}", (K,), -2.0, 2.0) if ln == 1 else None
+    x = big.to(dev)[:, 2:2 + K]
+    s_x = _hip.ln_split_scale(lnw, lnb, K, ln == 1)
+    xs = torch.full((B * K * N + 64,), float("nan"), device=dev)
+    ops.ln_split(x, xs, lnw.to(dev), lnb.to(dev) if ln == 1 else None, ln, s_x)
+    assert torch.isnan(xs[B * K * N:]).all()                                   # nothing written past the image
+    got = _unpack_presplit(xs[:B * K * N].cpu(), B * N, K).view(B, N, K).permute(0, 2, 1).reshape(B, K, H, W) / s_x
+    ref = _ln_ref(big[:, 2:2 + K].double(), lnw, lnb, ln)
+    err = float((got - ref).abs().max())
+    scale = float(ref.abs().max())
+    print(f"ln_split K{K} ln{ln} amp{amp:g}: s_x {s_x:g}  |ref|max {scale:.3e}  max-abs {err:.3e}")
+    assert torch.isfinite(got).all() and err <= 4e-7 * scale + 1e-9
+
+
+PS_CASES = [   # M, K, H, W, B, ln, bias, ct, mgroups, wg_shape
+    (576, 192, 16, 16, 2, 1, True, 6, 2, 0), (1020, 192, 16, 32, 1, 2, False, 8, 2, 42), (1020, 192, 16, 16, 3, 1, True, 8, 3, 32),
+    (1152, 384, 8, 16, 2, 1, False, 6, 4, 0), (2042, 384, 16, 8, 1, 2, True, 8, 4, 81), (2042, 384, 8, 16, 1, 1, False, 8, 3, 0),
+    (576, 192, 16, 16, 1, 1, False, 6, 1, 32), (570, 192, 16, 16, 1, 1, True, None, None, 0), (1152, 384, 16, 24, 2, 1, True, None, None, 0),
+    # pixel-tile counts that are no multiple of a workgroup's tiles (tail workgroup, workgroups straddling images)
+    (576, 192, 12, 12, 3, 1, True, 6, 2, 42), (1020, 192, 12, 12, 3, 2, True, 8, 1, 32), (1020, 192, 12, 20, 5, 1, False, 4, 3, 43),
+    (1152, 384, 12, 12, 3, 1, True, 8, 2, 81), (300, 192, 4, 4, 1, 1, True, 4, 1, 43),
+]
+
+
+@pytest.mark.parametrize("M,K,H,W,B,ln,bias,ct,mgroups,wg_shape", PS_CASES)
+def test_gemm_presplit(dev, M, K, H, W, B, ln, bias, ct, mgroups, wg_shape):
+    """LayerNorm + 1x1 conv with pre-split fp16 operands (irm_ln_split_f16 + irm_gemm_presplit_f16x3_f32) against
+    float64 and against the exact-f32 kernel pair (ln_stats + irm_gemm1x1_f32): the emulation must stay at fp32 rounding
+    level.  Output written into a channel slice of a sentinel-filled buffer (nothing outside it may change)."""
+    N = H * W
+    x = rnd(f"px{M}{K}{H}", (B, K, H, W), -2, 3)
+    w = rnd(f"pw{M}{K}", (M, K), -0.3, 0.3)
+    lnw = rnd(f"plw{K}", (K,), 0.5, 1.5)
+    lnb = rnd(f"plb{K}", (K,), -0.2, 0.2) if ln == 1 else None
+    bv = rnd(f"pb{M}", (M,), -0.3, 0.3) if bias else None
+    ref = torch.einsum("mk,bkhw->bmhw", w.double(), _ln_ref(x.double(), lnw, lnb, ln))
+    if bias:
+        ref = ref + bv.double().view(1, M, 1, 1)
+    xg = x.to(dev)
+    frag, s_w = _hip.pack_gemm_weight_presplit(w.to(dev))
+    assert float((_unpack_presplit(frag.cpu(), M, K) / s_w - w.double()).abs().max()) <= 2.0 ** -21 * float(w.abs().max())
+    s_x = _hip.ln_split_scale(lnw, lnb, K, ln == 1)
+    xs = torch.empty(B * K * N, device=dev)
+    ops.ln_split(xg, xs, lnw.to(dev), lnb.to(dev) if ln == 1 else None, ln, s_x)
+    ybig = torch.full((B, M + 7, H, W), 777.0, device=dev)
+    y16 = ybig[:, 3:3 + M]
+    ops.gemm_presplit(frag, xs, y16, M, K, out_scale=1.0 / (s_w * s_x), bias=bv.to(dev) if bias else None, ct=ct,
+                      mgroups=mgroups, wg_shape=wg_shape)
+    assert (ybig[:, :3] == 777.0).all() and (ybig[:, 3 + M:] == 777.0).all()
+    st = torch.empty(B, 2, N, device=dev)
+    ops.ln_stats(xg, st)
+    y32 = torch.empty(B, M, H, W, device=dev)
+    ops.gemm1x1(_hip.pack_gemm_weight(w).to(dev), xg, y32, M, K, bias=bv.to(dev) if bias else None, stats=st,
+                lnw=lnw.to(dev), lnb=lnb.to(dev) if ln == 1 else None, ln_mode=ln)
+    e16 = (y16.cpu().double() - ref).abs().max().item()
+    e32 = (y32.cpu().double() - ref).abs().max().item()
+    print(f"presplit M{M} K{K} N{N} B{B} ln{ln}: max-abs vs float64  f16x3 {e16:.3e}   f32 {e32:.3e}")
+    assert e16 < 2e-5 and e16 <= 2.0 * max(e32, 1e-7)
+    # run-to-run bit identity
+    y2 = torch.empty(B, M, H, W, device=dev)
+    ops.gemm_presplit(frag, xs, y2, M, K, out_scale=1.0 / (s_w * s_x), bias=bv.to(dev) if bias else None, ct=ct,
+                      mgroups=mgroups, wg_shape=wg_shape)
+    assert torch.equal(y2, y16)
+
+
+def test_gemm_presplit_trained_like(dev):
+    """Trained-like statistics: LayerNorm gains up to 30, weights spanning 1e-5 ... 10, activations x 1e-4 / 1 / 1e4 -
+    power-of-two scales on both operands keep the emulation within 2x of the exact-f32 kernel pair."""
+    M, K, H, W, B = 576, 192, 16, 16, 1
+    N = H * W
+    for ln in (1, 2):
+        for amp in (1e-4, 1.0, 1e4):
+            tag = f"pt{ln}{amp}"
+            x = rnd(tag + "x", (B, K, H, W), -1.5, 2.0) * amp
+            sign = torch.where(rnd(tag + "s", (M, K)) < 0, -1.0, 1.0)
+            w = sign * torch.exp(rnd(tag + "w", (M, K), np.log(1e-5), np.log(10.0)))
+            lnw = torch.exp(rnd(tag + "lw", (K,), np.log(0.1), np.log(30.0)))
+            lnb = rnd(tag + "lb", (K,), -2.0, 2.0) if ln == 1 else None
+            ref = torch.einsum("mk,bkhw->bmhw", w.double(), _ln_ref(x.double(), lnw, lnb, ln))
+            xg = x.to(dev)
+            frag, s_w = _hip.pack_gemm_weight_presplit(w.to(dev))
+            s_x = _hip.ln_split_scale(lnw, lnb, K, ln == 1)
+            xs = torch.empty(B * K * N, device=dev)
+            ops.ln_split(xg, xs, lnw.to(dev), lnb.to(dev) if ln == 1 else None, ln, s_x)
+            y16 = torch.empty(B, M, H, W, device=dev)
+            ops.gemm_presplit(frag, xs, y16, M, K, out_scale=1.0 / (s_w * s_x))
+            st = torch.empty(B, 2, N, device=dev)
+            ops.ln_stats(xg, st)
+            y32 = torch.empty(B, M, H, W, device=dev)
+            ops.gemm1x1(_hip.pack_gemm_weight(w).to(dev), xg, y32, M, K, stats=st, lnw=lnw.to(dev),
+                        lnb=lnb.to(dev) if ln == 1 else None, ln_mode=ln)
+            scale = float(ref.abs().max())
+            e16, e32 = float((y16.cpu().double() - ref).abs().max()), float((y32.cpu().double() - ref).abs().max())
+            print(f"presplit trained-like ln{ln} x{amp:g}: |ref|max {scale:.3e}  f16x3 {e16:.3e}  f32 {e32:.3e}")
+            assert torch.isfinite(y16).all() and e16 <= 2.0 * e32 + 4e-7 * scale
+
+
 @pytest.mark.parametrize("M,K,H,W,B,scale", [(192, 510, 8, 16, 2, 1.0), (384, 1021, 8, 8, 1, 1.0), (96, 255, 16, 16, 1, 3000.0)])
 def test_gemm1x1_f16x3_residual(dev, M, K, H, W, B, scale):
     """The emulated GEMM without the LayerNorm prologue (inputs pre-scaled by 2^-4 for the fp16 split) + bias +
