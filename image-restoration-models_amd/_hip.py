@@ -38,6 +38,7 @@ SIGNATURES = {
     "irm_mdta_finalize_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "irm_mdta_finalize_f16x3_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "irm_conv3x3_f32": [_P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "irm_conv3x3_thin_f32": [_P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "irm_conv3x3_f16x3_f32": [_P, _F, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "irm_tile_extract": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "irm_chan_stats_f32": [_P, _L, _P, _I, _I, _I, _F, _P],
@@ -324,18 +325,21 @@ class ConvWeight:
     """A 3x3 conv weight packed for both kernels: `exact` (irm_conv3x3_f32) always, `split` + `inv_scale`
     (irm_conv3x3_f16x3_f32) unless IRM_GEMM_EXACT is set; ops.conv3x3 picks the emulated kernel where its alignment
     requirements hold."""
-    __slots__ = ("exact", "split", "inv_scale")
+    __slots__ = ("exact", "split", "inv_scale", "raw")
 
-    def __init__(self, exact, split=None, inv_scale=1.0):
-        self.exact, self.split, self.inv_scale = exact, split, inv_scale
+    def __init__(self, exact, split=None, inv_scale=1.0, raw=None):
+        self.exact, self.split, self.inv_scale, self.raw = exact, split, inv_scale, raw
 
 
 def pack_conv3x3(w: torch.Tensor) -> ConvWeight:
     exact = pack_conv3x3_weight(w)
+    # convs with <= 4 channels on one side (image <-> features) run on the vector pipe, exact fp32, from the plain
+    # weight (irm_conv3x3_thin_f32): they are memory streams, not matrix work
+    raw = w.detach().float().contiguous() if min(w.shape[0], w.shape[1]) <= 4 else None
     if os.environ.get("IRM_GEMM_EXACT"):
-        return ConvWeight(exact)
+        return ConvWeight(exact, raw=raw)
     split, inv = pack_conv3x3_weight_split(w)
-    return ConvWeight(exact, split.to(w.device), inv)
+    return ConvWeight(exact, split.to(w.device), inv, raw=raw)
 
 
 def pack_dw_table(w9: torch.Tensor, bias, K: int, gate: bool) -> torch.Tensor:

@@ -319,6 +319,11 @@ def conv3x3(wp, x, y, ci: int, co: int, *, bias=None, relu1=False, res=None, res
     if isinstance(wp, _hip.ConvWeight):
         aligned = (W % 4 == 0 and _bs(x) % 4 == 0 and _bs(y) % 4 == 0 and _bs(res) % 4 == 0 and x.data_ptr() % 16 == 0
                    and y.data_ptr() % 16 == 0 and (res is None or res.data_ptr() % 16 == 0))
+        if wp.raw is not None and aligned and store_mode == 0 and not os.environ.get("IRM_NO_THIN_CONV"):
+            _launch("conv3x3_thin", 18.0 * B * ci * co * H * W, nbytes, "irm_conv3x3_thin_f32", _hip.ptr(wp.raw), _hip.ptr(x),
+                    _bs(x), _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), B, ci, co, H, W, int(relu1),
+                    int(res_mode), int(relu2), tag=f"ci{ci} co{co} {H}x{W} B{B}")
+            return
         wp = (wp.split, wp.inv_scale) if (wp.split is not None and aligned) else wp.exact
     if isinstance(wp, tuple):
         wps, inv_scale = wp

@@ -229,6 +229,15 @@ int irm_conv3x3_f32(const float* wp, const float* x, long x_bs, float* y, long y
                     const float* bias, int B, int Ci, int Co, int H, int W, int relu1, int res_mode, int relu2,
                     int store_mode, int ct, int ygroups, irm_stream_t stream);
 
+/* Dense 3x3 conv with <= 4 channels on one side (Co <= 4 or Ci <= 4), exact fp32 on the vector pipe (conv3x3_thin.hip):
+ * image <-> feature convs are memory streams.  w: the plain weight [Co][Ci][3][3] (device).  Epilogue as irm_conv3x3_f32
+ * (store_mode 0 only).  W % 4 == 0, 16-byte aligned tensors.  Replaces OverlapPatchEmbed and `output` (+ inp_img) of
+ * Restormer (restormer.py:156-164, 281), the first / last conv of DnCNN (network_dncnn.py:40-71) and REDNet
+ * (rednet.py:64-136), DeblurGANv2's `final` conv (fpn_mobilenet.py:68-70). */
+int irm_conv3x3_thin_f32(const float* w, const float* x, long x_bs, float* y, long y_bs, const float* res, long r_bs,
+                         const float* bias, int B, int Ci, int Co, int H, int W, int relu1, int res_mode, int relu2,
+                         irm_stream_t stream);
+
 /* irm_conv3x3_f32 as an fp32 emulation on the fp16 matrix cores (three v_mfma_f32_16x16x32_f16 per product: lo*hi,
  * hi*lo, hi*hi, fp32 accumulate; the staged halo tile is split ONCE per 32-channel stage into a channel-minor fp16 hi/lo
  * image in LDS and reused by 9 taps x all output tiles).  Same epilogue and store modes; needs W % 4 == 0 and 16-byte

@@ -587,6 +587,56 @@ def test_conv3x3_f16x3(dev, ci, co, H, W, B, bias, relu1, res_mode, relu2, store
     assert torch.all(y16[:, oc] == 7.0)
 
 
+THIN_CASES = [   # ci, co, H, W, B, bias, relu1, res_mode, relu2
+    (96, 3, 24, 40, 2, False, False, 1, False),      # Restormer output conv + inp_img
+    (3, 48, 24, 40, 1, False, False, 0, False),      # Restormer patch embed
+    (64, 1, 13, 20, 1, True, False, 2, False),       # DnCNN last layer: x - conv (odd height)
+    (1, 64, 13, 20, 2, True, True, 0, False),        # DnCNN first layer (gray) + ReLU
+    (128, 1, 16, 16, 1, True, False, 1, True),       # REDNet-style: + skip, ReLU
+    (4, 20, 5, 8, 1, True, False, 0, False),         # ci = 4, ragged co group
+    (50, 4, 9, 12, 3, False, True, 0, False),        # co = 4
+    (2, 2, 4, 4, 1, True, False, 3, False),          # both thin; tanh + clamp epilogue (DeblurGANv2 final)
+    (6, 2, 3, 36, 1, False, False, 0, False),        # fewer input channels than ci groups x 2
+]
+
+
+@pytest.mark.parametrize("ci,co,H,W,B,bias,relu1,res_mode,relu2", THIN_CASES)
+def test_conv3x3_thin(dev, ci, co, H, W, B, bias, relu1, res_mode, relu2):
+    """irm_conv3x3_thin_f32 (exact fp32 on the vector pipe, convs with <= 4 channels on one side) through ops.conv3x3's
+    dispatch on a ConvWeight, into a channel slice of a sentinel-filled buffer, against float64."""
+    tag = f"th{ci}_{co}_{H}_{W}"
+    w = rnd(tag + "w", (co, ci, 3, 3), -0.3, 0.3)
+    x = rnd(tag + "x", (B, ci, H, W), -1.5, 2.0)
+    bv = rnd(tag + "b", (co,)) if bias else None
+    r = rnd(tag + "r", (B, co, H, W)) if res_mode else None
+    ref = F.conv2d(x.double(), w.double(), None if bv is None else bv.double(), padding=1)
+    if relu1:
+        ref = F.relu(ref)
+    if res_mode == 1:
+        ref = ref + r.double()
+    elif res_mode == 2:
+        ref = r.double() - ref
+    elif res_mode == 3:
+        ref = torch.clamp(torch.tanh(ref) + r.double(), -1, 1)
+    if relu2:
+        ref = F.relu(ref)
+    cw = _hip.pack_conv3x3(w.to(dev))
+    assert cw.raw is not None
+    ybig = torch.full((B, co + 2, H, W), 5.0, device=dev)
+    timer, ops.TIMER = ops.TIMER, ops.KernelTimer()
+    try:
+        ops.conv3x3(cw, x.to(dev), ybig[:, 1:1 + co], ci, co, bias=None if bv is None else bv.to(dev), relu1=relu1,
+                    res=None if r is None else r.to(dev), res_mode=res_mode, relu2=relu2)
+        assert list(ops.TIMER.summary()) == ["conv3x3_thin"]           # the thin kernel ran, not a matrix-core one
+    finally:
+        ops.TIMER = timer
+    got = ybig.cpu().double()
+    err = float((got[:, 1:-1] - ref).abs().max())
+    print(f"conv3x3 thin {tag}: max-abs vs float64 {err:.3e}")
+    assert err <= 2e-6 * max(1.0, float(ref.abs().max()))
+    assert torch.all(got[:, 0] == 5.0) and torch.all(got[:, -1] == 5.0)
+
+
 # --------------------------------------------------------------------------- no writes outside the output
 def _guarded(dev, shape, pad=1 << 14):
     n = int(np.prod(shape))
