@@ -150,6 +150,11 @@ ROOFLINE_KERNELS = {
                      r"^lnpw_dw_fused_kernel<.*, false>"),
     "gemm1x1_f16x3": ("gemm_xres_kernel / gemm_ring_kernel<F16> (irm_gemm1x1_f16x3_f32: LayerNorm + 1x1 conv, fp32 emulated "
                       "by three fp16 MFMAs, fp32 accumulate)", "hbm", r"^(gemm_ring_kernel<.*, true>|gemm_xres_kernel)"),
+    "gemm_ps_f16x3": ("gemm_ps_kernel (irm_gemm_presplit_f16x3_f32: 1x1 conv on pre-split fp16 hi/lo fragments of LayerNorm(x), "
+                      "C >= 192 levels; three fp16 MFMAs per product, fp32 accumulate)", "hbm", r"^gemm_ps_kernel"),
+    "ln_split": ("ln_split_kernel (irm_ln_split_f16: LayerNorm + fp16 hi/lo split in MFMA fragment order)", "hbm", r"^ln_split_kernel"),
+    "conv3x3_thin": ("conv3x3_thin_{in,out}_kernel (irm_conv3x3_thin_f32: 3x3 convs with <= 4 channels on one side, exact fp32 "
+                     "on the vector pipe)", "hbm", r"^conv3x3_thin"),
     "gemm1x1": ("gemm_ring_kernel (irm_gemm1x1_f32, exact f32 MFMA)", "mfma", r"^gemm_(ring_kernel<.*, false>|pw_kernel.*)$"),
     "dwgemm": ("dwgemm_kernel (irm_dwgemm_f32)", "mfma", r"^dwgemm_kernel"),
     "conv3x3": ("conv3x3_ring_kernel (irm_conv3x3_f32)", "mfma", r"^conv3x3_"),
@@ -297,7 +302,7 @@ def main():
             dom = max(ks, key=lambda k: ks[k]["ms"])
             g = ks[dom]
             label, bound, pmc_re = ROOFLINE_KERNELS.get(dom, (dom, "hbm", None))
-            emulated = dom in ("gdfn_fused", "qkv_dw_fused", "gemm1x1_f16x3", "dwgemm_f16x3")
+            emulated = dom in ("gdfn_fused", "qkv_dw_fused", "gemm1x1_f16x3", "dwgemm_f16x3", "gemm_ps_f16x3")
             if bound == "mfma" and emulated:
                 # the unit that executes the arithmetic is the fp16 matrix core: three MFMA passes per fp32 product
                 ach, peak, unit = 3.0 * g["flops"] / (g["ms"] * 1e-3) / 1e12, PEAK_F16_MFMA_TFLOPS, "TFLOP/s"

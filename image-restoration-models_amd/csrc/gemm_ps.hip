@@ -228,13 +228,23 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_ps_kernel(PsArgs a) {
         }
     }
 
+    // The workgroups sweep their output-tile chunks in ROTATED order (workgroup i starts at chunk i mod nc): started
+    // together on the same order, all 256 CUs would request the same few KiB of the weight fragments at every moment -
+    // one or two L2 channels per XCD serving everybody - instead of spreading their reads over the whole matrix.
+#ifdef PS_NO_ROTATE
+    const int rot = 0;
+#else
+    const int rot = pb % nc;
+#endif
+    auto cm = [&](int c) { const int cc = c + rot; return c0 + (cc >= nc ? cc - nc : cc); };
+
     // stage (c, ks) -> ring slot (c KS + ks) % NS
     auto issue = [&](int c, int ks) {
         char* dst = smem + ((c * KS + ks) & (NS - 1)) * STG;
 #pragma unroll
         for (int j = 0; j < DPW; ++j) {
             const int f = (wave + NW * j) % FR;
-            const int mt = min((c0 + c) * CT + (f >> 1), a.mtiles - 1);
+            const int mt = min(cm(c) * CT + (f >> 1), a.mtiles - 1);
             const _Float16* src = a.wps + (((long)mt * KS + ks) * 2 + (f & 1)) * 512 + lane * 8;
             if (IRM_DBG(a.dbg, 4)) src = a.wps + lane * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -321,9 +331,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_ps_kernel(PsArgs a) {
         // ---- chunk epilogue: exactly ST store instructions per wave (masked rows go to the dump page)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const int co = ((c0 + c) * CT + ct) * 16 + r;
+            const int co = (cm(c) * CT + ct) * 16 + r;
             const bool ok = co < a.M && !IRM_DBG(a.dbg, 1);
-            const float bv = lbias[(c * CT + ct) * 16 + r];
+            const float bv = lbias[((cm(c) - c0) * CT + ct) * 16 + r];
 #pragma unroll
             for (int p = 0; p < WP; ++p) {
                 const float4 v = make_float4(fmaf(acc[p][ct][0], a.out_scale, bv), fmaf(acc[p][ct][1], a.out_scale, bv),
@@ -380,6 +390,8 @@ extern "C" int irm_gemm_presplit_f16x3_f32(const void* wps, const void* xs, floa
         if (wg_shape == 43 && ct == 4) return ps_launch<6, 3, 4, 2, 4>(a, stream);
         return IRM_EINVAL;
     }
+    if (wg_shape == 41 && ct == 8) return ps_launch<12, 1, 8, 4, 4>(a, stream);
+    if (wg_shape == 41 && ct == 6) return ps_launch<12, 1, 6, 3, 4>(a, stream);
     if (wg_shape == 81 && ct == 8) return ps_launch<12, 1, 8, 4, 8>(a, stream);
     if (wg_shape == 81 && ct == 6) return ps_launch<12, 1, 6, 3, 8>(a, stream);
     return IRM_EINVAL;

@@ -48,7 +48,7 @@ for (M, K, H, W) in [(1020, 192, 128, 128), (576, 192, 128, 128), (2042, 384, 64
           f"| old vs new max-abs {err:.1e}", flush=True)
     if "--plans" in sys.argv:
         mt = (M + 15) // 16
-        shapes = [(42, 8), (42, 6), (32, 8), (32, 6), (43, 4)] if K == 192 else [(81, 8), (81, 6)]
+        shapes = [(42, 8), (42, 6), (32, 8), (32, 6), (43, 4)] if K == 192 else [(81, 8), (81, 6), (41, 8), (41, 6)]
         for shp, ct in shapes:
             chunks = -(-mt // ct)
             for mg in (1, 2, 3, 4):
