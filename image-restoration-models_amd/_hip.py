@@ -27,6 +27,8 @@ SIGNATURES = {
     "irm_gemm1x1_f16x3_f32": [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P],
     "irm_ln_split_f16": [_P, _L, _P, _P, _I, _F, _F, _P, _I, _I, _I, _P],
     "irm_gemm_presplit_f16x3_f32": [_P, _P, _P, _L, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "irm_dwconv3x3_gate_split_f16": [_P, _L, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
+    "irm_gemm_presplit_res_f16x3_f32": [_P, _P, _P, _L, _P, _L, _P, _F, _I, _I, _I, _I, _I, _P],
     "irm_dwconv3x3_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
     "irm_dwconv3x3_gate_f32": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "irm_dwgemm_f32": [_P, _L, _P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P, _F, _P],
@@ -154,12 +156,15 @@ def _pow2_floor(v: float) -> float:
     return 2.0 ** math.floor(math.log2(v))
 
 
-def pack_gemm_weight_presplit(w: torch.Tensor):
+def pack_gemm_weight_presplit(w: torch.Tensor, k_pad: int | None = None):
     """W [M][K] (K % 32 == 0) -> (fragments, s_w) for irm_gemm_presplit_f16x3_f32: W s_w split into fp16 hi + lo with the
     power of two s_w chosen so that max|W| s_w lies in [2^13, 2^14) (the lo parts stay normal fp16 numbers for weights
     of any magnitude), in MFMA fragment order [mtile][k-step][hi|lo][lane = 16 g + m][e] = part[16 mtile + m][32 ks + 8 g + e]
-    (rows beyond M zero).  Returned as a float32 view (two halves per element)."""
+    (rows beyond M zero; k_pad: zero columns up to that K, a multiple of 32).  Returned as a float32 view (two halves
+    per element)."""
     w = w.detach().reshape(w.shape[0], -1).float()
+    if k_pad is not None and k_pad > w.shape[1]:
+        w = torch.cat([w, torch.zeros(w.shape[0], k_pad - w.shape[1], dtype=w.dtype, device=w.device)], dim=1)
     m, k = w.shape
     assert k % 32 == 0
     mt, ks = (m + 15) // 16, k // 32

@@ -396,3 +396,339 @@ extern "C" int irm_gemm_presplit_f16x3_f32(const void* wps, const void* xs, floa
     if (wg_shape == 81 && ct == 6) return ps_launch<12, 1, 6, 3, 8>(a, stream);
     return IRM_EINVAL;
 }
+
+// ===============================================================================================================
+// GDFN tail of the C >= 192 levels with pre-split operands (late round 2):
+//   irm_dwconv3x3_gate_split_f16 : g = gelu(dw(h1)) * dw(h2) (restormer.py:84, 89-91) written as fp16 hi + lo of g * 2^-4 in
+//       MFMA fragment order gs[pixel tile][k-step of 32 gate channels][hi | lo][64 lanes][8 halves] (channels beyond
+//       hid: zero) - the bytes of the planar fp32 tensor irm_dwconv3x3_gate_f32 writes, but the GEMM that consumes them
+//       needs no conversion and reads 1 KiB per instruction.  A workgroup = 32 gate channels x 8 rows x 32 columns:
+//       thread (channel, column quad) slides the 3-row window of irm_dwconv3x3_f32 down 8 rows (128-byte row segments
+//       per channel), parks its 32 results in LDS [pixel][channel], the waves then emit whole fragments.
+//   irm_gemm_presplit_res_f16x3_f32 : y = res + bias + out_scale * (W gs)  (FeedForward.project_out + the block's
+//       residual, restormer.py:86, 92, 148), K streamed: every wave owns WP pixel tiles and ALL output tiles (12 per
+//       ring stage); its own gs fragments come straight from global memory into a register rotation (two k-steps
+//       ahead), the weight fragments of a stage (12 tiles x hi/lo = 24 KiB) through a 3-deep LDS-DMA ring.
+//       Counted vmcnt: at the top of a stage the wave's younger operations are one stage of DMA and one or two
+//       k-steps of fragment loads - compile-time constants (stages past the end re-request the last one).
+struct GateSplitArgs {
+    const float* x; long x_bs;     // [B][2 hid][H][W]
+    const float* w;                // [2 hid][9]
+    const float* bias;             // [2 hid] or null
+    _Float16* gs;                  // [B * N / 16][KS][2][64][8]
+    int hid, H, W, KS, tiles_x;
+    float scale;
+};
+
+__device__ __forceinline__ void gs_row(const float* plane, int row, int H, int W, int col, float (&r)[6]) {
+    if (row < 0 || row >= H) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = 0.0f;
+        return;
+    }
+    const float* p = plane + (long)row * W;
+    const float4 v = *reinterpret_cast<const float4*>(p + col);
+    r[0] = col > 0 ? p[col - 1] : 0.0f;
+    r[1] = v.x; r[2] = v.y; r[3] = v.z; r[4] = v.w;
+    r[5] = col + 4 < W ? p[col + 4] : 0.0f;
+}
+
+__device__ __forceinline__ void gs_apply(const float (&k)[9], const float (&r0)[6], const float (&r1)[6],
+                                         const float (&r2)[6], float bias, float (&o)[4]) {
+    // (the operation order of dw_apply in elementwise.hip: the two kernels give identical values)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float s = bias;
+        s += k[0] * r0[i] + k[1] * r0[i + 1] + k[2] * r0[i + 2];
+        s += k[3] * r1[i] + k[4] * r1[i + 1] + k[5] * r1[i + 2];
+        s += k[6] * r2[i] + k[7] * r2[i + 1] + k[8] * r2[i + 2];
+        o[i] = s;
+    }
+}
+
+// CH gate channels x (1024 / CH) columns x 8 rows per workgroup: thread = (channel, column quad).  CH 8: a wave reads
+// 512-byte row segments of one plane (the access pattern of irm_dwconv3x3_gate_f32) and the workgroup emits quarter
+// fragments (256-byte runs); CH 32: 128-byte row segments, whole fragments.
+template <int CH>
+__global__ __launch_bounds__(256) void dwconv3x3_gate_split_kernel(GateSplitArgs a) {
+    constexpr int CGS = 256 / CH, COLS = 4 * CGS;  // column quads / columns per workgroup
+    constexpr int PXS = 8 * COLS + 4;              // floats per channel row of the LDS tile [channel][pixel] (+ pad)
+    __shared__ __attribute__((aligned(16))) float tile[CH * PXS];
+    const int tid = threadIdx.x;
+    const int cgl = tid % CGS, chl = tid / CGS;
+    const int b = blockIdx.z;
+    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+    const int y0 = ty * 8, x0 = tx * COLS;
+    const int c = blockIdx.y * CH + chl;           // gate channel
+    const long plane = (long)a.H * a.W;
+    const int col = x0 + 4 * cgl;
+    const bool live = c < a.hid && col < a.W;
+    if (live) {
+        const float* xa = a.x + (long)b * a.x_bs + (long)c * plane;
+        const float* xb = xa + (long)a.hid * plane;
+        float ka[9], kb[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { ka[i] = a.w[c * 9 + i]; kb[i] = a.w[(c + a.hid) * 9 + i]; }
+        const float ba = a.bias ? a.bias[c] : 0.0f, bb = a.bias ? a.bias[c + a.hid] : 0.0f;
+        float a0[6], a1[6], a2[6], b0[6], b1[6], b2[6];
+        gs_row(xa, y0 - 1, a.H, a.W, col, a0);
+        gs_row(xa, y0, a.H, a.W, col, a1);
+        gs_row(xb, y0 - 1, a.H, a.W, col, b0);
+        gs_row(xb, y0, a.H, a.W, col, b1);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int y = y0 + r;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y < a.H) {
+                gs_row(xa, y + 1, a.H, a.W, col, a2);
+                gs_row(xb, y + 1, a.H, a.W, col, b2);
+                float u[4], v[4];
+                gs_apply(ka, a0, a1, a2, ba, u);
+                gs_apply(kb, b0, b1, b2, bb, v);
+                o = make_float4(irm_gelu(u[0]) * v[0], irm_gelu(u[1]) * v[1], irm_gelu(u[2]) * v[2], irm_gelu(u[3]) * v[3]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { a0[i] = a1[i]; a1[i] = a2[i]; b0[i] = b1[i]; b1[i] = b2[i]; }
+            }
+            *reinterpret_cast<float4*>(tile + chl * PXS + r * COLS + 4 * cgl) = o;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            *reinterpret_cast<float4*>(tile + chl * PXS + r * COLS + 4 * cgl) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    // emission: unit = (pixel tile, lane group g8 of the workgroup's CH / 8, pixel i): 16 bytes of the hi and of the lo
+    // fragment; consecutive threads -> consecutive pixels, then lane groups: 256-byte runs per (tile, part, lane group)
+    constexpr int G8 = CH / 8, TILES = 8 * COLS / 16;
+    const long ptl = plane >> 4;
+    const int ks = (blockIdx.y * CH) >> 5, g8_0 = ((blockIdx.y * CH) & 31) >> 3;
+#pragma unroll
+    for (int t = 0; t < TILES * G8 * 16 / 256; ++t) {
+        const int u = tid + 256 * t;
+        const int i16 = u & 15, g8l = (u >> 4) % G8, lt = u / (16 * G8);
+        const int row = lt / (COLS / 16), seg = lt - row * (COLS / 16);
+        if (y0 + row >= a.H || x0 + seg * 16 >= a.W) continue;
+        const float* src = tile + (8 * g8l) * PXS + row * COLS + seg * 16 + i16;
+        ps_h8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = fminf(fmaxf(__fmul_rn(src[e * PXS], a.scale), -65000.0f), 65000.0f);
+            asm volatile("" : "+v"(y));            // one rounded fp32 value for both parts (see ln_split_kernel)
+            const _Float16 hh = (_Float16)y;
+            h[e] = hh;
+            l[e] = (_Float16)(y - (float)hh);
+        }
+        const long pt = (long)b * ptl + (((long)(y0 + row) * a.W + x0 + seg * 16) >> 4);
+        _Float16* out = a.gs + ((pt * a.KS + ks) * 2) * 512 + ((g8_0 + g8l) * 16 + i16) * 8;
+        *reinterpret_cast<ps_h8*>(out) = h;
+        *reinterpret_cast<ps_h8*>(out + 512) = l;
+    }
+}
+
+template <int CH>
+static int gate_split_launch(GateSplitArgs a, int B, hipStream_t stream) {
+    constexpr int COLS = 1024 / CH;
+    a.tiles_x = (a.W + COLS - 1) / COLS;
+    const int cgroups = a.KS * (32 / CH);          // channel groups incl. the zero channels up to 32 KS
+    if (cgroups > 65535) return IRM_EINVAL;
+    const dim3 grid((unsigned)(a.tiles_x * ((a.H + 7) / 8)), cgroups, B);
+    hipLaunchKernelGGL(dwconv3x3_gate_split_kernel<CH>, grid, dim3(256), 0, stream, a);
+    return irm_launch_status();
+}
+
+// ch: gate channels per workgroup (8, 16 or 32; 0 = by row length: whole 512-byte row segments where W >= 128)
+extern "C" int irm_dwconv3x3_gate_split_f16(const float* x, long x_bs, const float* w, const float* bias, void* gs,
+                                            float scale, int B, int hid, int H, int W, int ch, hipStream_t stream) {
+    if (!x || !w || !gs || B <= 0 || hid <= 0 || H <= 0 || W <= 0 || B > 65535) return IRM_EINVAL;
+    if ((W & 15) || (x_bs & 3) || !irm_aligned16(x) || !irm_aligned16(gs) || !(scale > 0.0f)) return IRM_EINVAL;
+    GateSplitArgs a{x, x_bs, w, bias, reinterpret_cast<_Float16*>(gs), hid, H, W, (hid + 31) / 32, 0, scale};
+    if (ch == 0) ch = W >= 128 ? 8 : (W >= 64 ? 16 : 32);
+    switch (ch) {
+        case 8: return gate_split_launch<8>(a, B, stream);
+        case 16: return gate_split_launch<16>(a, B, stream);
+        case 32: return gate_split_launch<32>(a, B, stream);
+        default: return IRM_EINVAL;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct Ps2Args {
+    const _Float16* xs;            // [npt][KS][2][64][8]
+    const _Float16* wps;           // [mtiles][KS][2][64][8]
+    const float* bias;             // [M] or null
+    const float* res; long r_bs;   // [B][M][N] or null (may alias y)
+    float* y; long y_bs;           // [B][M][N]
+    int M, N, KS, mtiles, npt;
+    float out_scale;
+};
+
+// NH = ring stages per k-step (12 output tiles each: M <= 192 NH, zero tiles beyond M are clamped), WP pixel tiles per
+// wave, NW waves.
+template <int NH, int WP, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_ps2_kernel(Ps2Args a) {
+    constexpr int NS = 3, MTS = 12, FR = 2 * MTS, STG = FR * 1024;
+    constexpr int DPW = FR / NW;                   // DMA instructions per wave and stage
+    constexpr int CG = 2, NG = MTS / CG;           // weight fragments in register groups of 2 tiles, two groups in flight
+    static_assert(FR % NW == 0 && NG % 2 == 0, "shape");
+    // Operation order of a wave: every stage issues [DMA(s + 2)] and, on the first stage of k-step k, [A(k + 2)] behind
+    // it.  At the top of stage s the wave needs DMA(s) and A(k) - whichever was issued later has exactly one stage of
+    // DMA and one k-step of fragment loads behind it (NH 1: D(s) A(s) | D(s+1) A(s+1); NH 2, first half: D(s) A(k+1)
+    // D(s+1) with A(k) older; second half: D(s) | D(s+1) A(k+2)).
+    constexpr int YOUNGER = DPW + 2 * WP;
+    static_assert(NS * DPW + 8 * WP <= 63, "vmcnt field");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, r = lane & 15;
+    const int nblk = gridDim.x;
+    int pb = blockIdx.x;
+    if ((nblk & 7) == 0) pb = (pb & 7) * (nblk >> 3) + (pb >> 3);     // XCD x: one contiguous eighth of the pixel range
+    const int ptl = a.N >> 4;
+    int pt_idx[WP];
+    bool pt_ok[WP];
+#pragma unroll
+    for (int p = 0; p < WP; ++p) {
+        const int pt = (pb * NW + wave) * WP + p;
+        pt_ok[p] = pt < a.npt;
+        pt_idx[p] = min(pt, a.npt - 1);
+    }
+    const int TOT = a.KS * NH;                     // ring stages; a.KS % 4 == 0 (host)
+
+    auto issue = [&](int s) {                      // stage s = (k-step s / NH, tile half s % NH); past the end: the last one
+        const int sc = min(s, TOT - 1);
+        const int ks = sc / NH, half = sc - ks * NH;
+        char* dst = smem + (s % NS) * STG;
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int f = wave + NW * j;
+            const int mt = min(half * MTS + (f >> 1), a.mtiles - 1);
+            const _Float16* src = a.wps + (((long)mt * a.KS + ks) * 2 + (f & 1)) * 512 + lane * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+        }
+    };
+    ps_h8 xh[4][WP], xl[4][WP];                    // k-step ks lives in set ks % 4
+    auto load_a = [&](int ks, int set) {
+        const int kc = min(ks, a.KS - 1);
+#pragma unroll
+        for (int p = 0; p < WP; ++p) {
+            const _Float16* xp = a.xs + ((long)pt_idx[p] * a.KS + kc) * 1024 + lane * 8;
+            xh[set][p] = *reinterpret_cast<const ps_h8*>(xp);
+            xl[set][p] = *reinterpret_cast<const ps_h8*>(xp + 512);
+        }
+    };
+    f32x4 acc[WP][NH * MTS];
+#pragma unroll
+    for (int p = 0; p < WP; ++p)
+#pragma unroll
+        for (int c = 0; c < NH * MTS; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ps_h8 wh[2][CG], wl[2][CG];
+    auto read_group = [&](int slot, int jg, int set) {
+        const char* base = smem + slot * STG + jg * CG * 2048 + lane * 16;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            wh[set][c] = *reinterpret_cast<const ps_h8*>(base + c * 2048);
+            wl[set][c] = *reinterpret_cast<const ps_h8*>(base + c * 2048 + 1024);
+        }
+    };
+
+    // prologue in the operation order of the steady state: A(0) D(0) A(1) D(1)
+    load_a(0, 0);
+    issue(0);
+    load_a(1, 1);
+    issue(1);
+    int s = 0;
+    for (int k4 = 0; k4 < a.KS; k4 += 4) {
+        ps_static_for<4>([&](auto kk_c) {
+            constexpr int kk = decltype(kk_c)::value;
+            ps_static_for<NH>([&](auto h_c) {
+                constexpr int half = decltype(h_c)::value;
+                // own DMAs of stage s (and, older, the fragments of this k-step) have landed; everybody is done with s - 1
+                ps_wait_vmcnt<YOUNGER>();
+                asm volatile("s_barrier" ::: "memory");
+                issue(s + 2);
+                if (half == 0) load_a(k4 + kk + 2, (kk + 2) & 3);
+                const int slot = s % NS;
+                read_group(slot, 0, 0);
+#pragma unroll
+                for (int jg = 0; jg < NG; ++jg) {
+                    if (jg + 1 < NG) read_group(slot, jg + 1, (jg + 1) & 1);
+                    const int set = jg & 1;
+#pragma unroll
+                    for (int cc = 0; cc < CG; ++cc)
+#pragma unroll
+                        for (int p = 0; p < WP; ++p) {
+                            f32x4& ac = acc[p][half * MTS + jg * CG + cc];
+                            ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[kk][p], wh[set][cc], ac, 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int cc = 0; cc < CG; ++cc)
+#pragma unroll
+                        for (int p = 0; p < WP; ++p) {
+                            f32x4& ac = acc[p][half * MTS + jg * CG + cc];
+                            ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[kk][p], wl[set][cc], ac, 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int cc = 0; cc < CG; ++cc)
+#pragma unroll
+                        for (int p = 0; p < WP; ++p) {
+                            f32x4& ac = acc[p][half * MTS + jg * CG + cc];
+                            ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[kk][p], wh[set][cc], ac, 0, 0, 0);
+                        }
+                }
+                ++s;
+            });
+        });
+    }
+    ps_wait_vmcnt<0>();                            // the two re-requested stages: no LDS-DMA in flight at exit
+    // ---- epilogue: + bias + residual, 16-byte stores (pixels on the MFMA row index)
+#pragma unroll
+    for (int p = 0; p < WP; ++p) {
+        if (!pt_ok[p]) continue;
+        const int bi = pt_idx[p] / ptl;
+        const long poff = (long)(pt_idx[p] - bi * ptl) * 16 + g * 4;
+        float* Y = a.y + (long)bi * a.y_bs + poff;
+        const float* R = a.res ? a.res + (long)bi * a.r_bs + poff : nullptr;
+#pragma unroll
+        for (int c = 0; c < NH * MTS; ++c) {
+            const int co = c * 16 + r;
+            if (co >= a.M) continue;
+            const float bv = a.bias ? a.bias[co] : 0.0f;
+            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (R) rv = *reinterpret_cast<const float4*>(R + (long)co * a.N);
+            *reinterpret_cast<float4*>(Y + (long)co * a.N) =
+                make_float4(fmaf(acc[p][c][0], a.out_scale, bv) + rv.x, fmaf(acc[p][c][1], a.out_scale, bv) + rv.y,
+                            fmaf(acc[p][c][2], a.out_scale, bv) + rv.z, fmaf(acc[p][c][3], a.out_scale, bv) + rv.w);
+        }
+    }
+}
+
+template <int NH, int WP, int NW>
+static int ps2_launch(const Ps2Args& a, hipStream_t stream) {
+    const int nblk = (a.npt + NW * WP - 1) / (NW * WP);
+    const size_t lds = (size_t)3 * 24 * 1024;
+    IRM_ALLOW_BIG_LDS((&gemm_ps2_kernel<NH, WP, NW>));
+    hipLaunchKernelGGL((gemm_ps2_kernel<NH, WP, NW>), dim3(nblk), dim3(NW * 64), lds, stream, a);
+    return irm_launch_status();
+}
+
+// xs: fragments of the K = 32 KS input channels (irm_dwconv3x3_gate_split_f16; channels beyond the real ones zero);
+// wps: W s_w (columns padded to K) split by the host in fragment order (_hip.pack_gemm_weight_presplit); out_scale =
+// 1 / (s_w s_x).  M <= 384, KS % 4 == 0, N % 16 == 0.  wg_shape = 10 waves + pixel tiles per wave: M <= 192: 42 (default)
+// or 82; M <= 384: 81 (default) or 41.
+extern "C" int irm_gemm_presplit_res_f16x3_f32(const void* wps, const void* xs, float* y, long y_bs, const float* res,
+                                               long r_bs, const float* bias, float out_scale, int B, int M, int KS, int N,
+                                               int wg_shape, hipStream_t stream) {
+    if (!wps || !xs || !y || B <= 0 || M <= 0 || M > 384 || KS <= 0 || (KS & 3) || N <= 0) return IRM_EINVAL;
+    if ((N & 15) || (y_bs & 3) || (r_bs & 3) || !irm_aligned16(y) || !irm_aligned16(res) || !irm_aligned16(xs)
+        || !irm_aligned16(wps)) return IRM_EINVAL;
+    Ps2Args a{reinterpret_cast<const _Float16*>(xs), reinterpret_cast<const _Float16*>(wps), bias, res, r_bs, y, y_bs,
+              M, N, KS, (M + 15) / 16, (int)((long)B * N / 16), out_scale};
+    if (M <= 192) {
+        if (wg_shape == 0 || wg_shape == 42) return ps2_launch<1, 2, 4>(a, stream);
+        if (wg_shape == 82) return ps2_launch<1, 2, 8>(a, stream);
+        return IRM_EINVAL;
+    }
+    if (wg_shape == 41) return ps2_launch<2, 1, 4>(a, stream);
+    if (wg_shape == 0 || wg_shape == 81) return ps2_launch<2, 1, 8>(a, stream);      // (measured: 66 vs 73 us, M 384 on 6 x 64^2)
+    return IRM_EINVAL;
+}

@@ -168,6 +168,40 @@ def gemm_presplit(wps: torch.Tensor, xs: torch.Tensor, y: torch.Tensor, M: int, 
             int(mgroups), int(wg_shape), tag=f"M{M} K{K} N{N} B{B} ct{ct} mg{mgroups}")
 
 
+GATE_SPLIT_SCALE = 0.0625      # 2^-4: gated activations up to ~1e6 stay inside fp16 (as irm_gemm1x1_f16x3_f32 without LN)
+
+
+def can_gate_split(M: int, hid: int, W: int, N: int) -> bool:
+    """GDFN tail on pre-split operands (gemm_ps.hip): gate -> fragments -> K-streamed GEMM; the C >= 192 levels."""
+    return 96 < M <= 384 and W % 16 == 0 and N % 16 == 0 and (-(-hid // 32)) % 4 == 0
+
+
+def dwconv3x3_gate_split(x, w9, gs, *, bias=None, scale: float = GATE_SPLIT_SCALE, ch: int = 0):
+    """gs = fp16 hi/lo fragments of gelu(dw(x[:, :hid])) * dw(x[:, hid:]) * scale (irm_dwconv3x3_gate_split_f16);
+    gs: flat float32 buffer of B * 32 ceil(hid/32) * H * W elements."""
+    _chk(x, "x")
+    B, C2, H, W = x.shape
+    hid = C2 // 2
+    kp = 32 * -(-hid // 32)
+    assert gs.numel() >= B * kp * H * W and gs.is_contiguous() and gs.dtype == torch.float32
+    _launch("dwconv3x3_gate_split", 18.0 * B * C2 * H * W, 4.0 * B * (C2 + kp) * H * W, "irm_dwconv3x3_gate_split_f16",
+            _hip.ptr(x), _bs(x), _hip.ptr(w9), _hip.ptr(bias), _hip.ptr(gs), float(scale), B, hid, H, W, int(ch),
+            tag=f"hid{hid} {H}x{W} B{B}")
+
+
+def gemm_presplit_res(wps, xs, y, M: int, KS: int, *, out_scale: float, res=None, bias=None, wg_shape: int = 0):
+    """y = res + bias + (W xs) * out_scale, K = 32 KS streamed (irm_gemm_presplit_res_f16x3_f32); y may be res."""
+    _chk(y, "y")
+    B, _, H, W = y.shape
+    N = H * W
+    assert y.shape[1] >= M and xs.numel() >= B * 32 * KS * N
+    if res is not None:
+        _chk(res, "res")
+    _launch("gemm_ps_res_f16x3", 2.0 * B * M * 32 * KS * N, 4.0 * B * N * (32 * KS + M + (M if res is not None else 0)),
+            "irm_gemm_presplit_res_f16x3_f32", _hip.ptr(wps), _hip.ptr(xs), _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res),
+            _hip.ptr(bias), float(out_scale), B, M, KS, N, int(wg_shape), tag=f"M{M} K{32 * KS} N{N} B{B}")
+
+
 def dwconv3x3(x, w9, y, *, bias=None, act=ACT_NONE):
     """Depth-wise 3x3 (+bias, +activation); w9: [C, 9]."""
     _chk(x, "x"), _chk(y, "y")

@@ -193,6 +193,10 @@ class Restormer(nn.Module):
                     if _hip.split_is_safe(ff.project_out.weight):
                         pk[name]["pout_s"] = _hip.pack_gemm_weight_split(ff.project_out.weight)
                     pk[name]["mfold_split"] = _hip.split_is_safe(a.project_out.weight)
+                    if ops.can_gate_split(m.dim, ff.hidden, 16, 16):
+                        # GDFN tail on pre-split operands (gemm_ps.hip): project_out fragments, K padded to 32 ceil(hid / 32)
+                        frag, s_w = _hip.pack_gemm_weight_presplit(ff.project_out.weight, k_pad=32 * -(-ff.hidden // 32))
+                        pk[name]["pout_ps"] = (frag, 1.0 / (s_w * ops.GATE_SPLIT_SCALE))
                     if m.dim in (192, 384):
                         # LayerNorm + qkv / project_in with pre-split operands (gemm_ps.hip): (fragments, 1 / (s_w s_x), s_x);
                         # power-of-two scales on both operands - no range guard needed
@@ -321,7 +325,17 @@ class Restormer(nn.Module):
             ops.gemm1x1(w["pin_s" if s_pin else "pin"], x, h, 2 * hid, C, bias=w["pin_b"], stats=stats, lnw=w["n2w"],
                         lnb=w["n2b"], ln_mode=blk.norm2.mode, split=s_pin)
         emit = fuse and want_stats
-        if fuse_dw:
+        if (split and "pout_ps" in w and not emit and ops.can_gate_split(C, hid, W, N) and C > 192
+                and not os.environ.get("IRM_NO_GATE_SPLIT")):
+            # gate -> fp16 hi/lo fragments (the bytes of g), then a K-streamed matrix-core GEMM in place on x.  Only at
+            # C = 384 (6 x 64^2 in the model: 87 + 85 us against 65 + 126 us); at C = 192 the fragment-writing gate kernel
+            # loses more (174 vs 138 us) than the GEMM gains (107 vs 116 us)
+            frag, out_scale = w["pout_ps"]
+            ks = -(-hid // 32)
+            gs = self._buf("gsplit", B * 32 * ks * N, dev)
+            ops.dwconv3x3_gate_split(h, w["ffn_dw"], gs, bias=w["ffn_dw_b"])
+            ops.gemm_presplit_res(frag, gs, x, C, ks, out_scale=out_scale, res=x, bias=w["pout_b"])
+        elif fuse_dw:
             ops.dwgemm(w["pout_s" if s_pout else "pout"], w["ffn_dwp"], h, x, C, hid, gate=True, res=x,
                        bias=w["pout_b"], stats_out=stats if emit else None, split=s_pout)
         else:

@@ -115,6 +115,22 @@ int irm_gemm_presplit_f16x3_f32(const void* wps, const void* xs, float* y, long 
                                 int act, int B, int M, int K, int N, int ct, int mgroups, int wg_shape,
                                 irm_stream_t stream);
 
+/* GDFN tail of the C >= 192 levels on pre-split operands (gemm_ps.hip):
+ * irm_dwconv3x3_gate_split_f16: gs = fp16 hi + lo of gelu_erf(dw(x[c])) * dw(x[c + hid]) * scale in MFMA fragment order
+ *   gs [B * H W / 16][ceil(hid/32)][hi | lo][64 lanes][8 halves] (lane = 16 g + i: pixel 16 tile + i, gate channel
+ *   32 ks + 8 g + e; channels beyond hid zero; values clamped at +-65000) - replaces FeedForward.dwconv + chunk +
+ *   F.gelu(x1) * x2 (restormer.py:84, 89-91) where the consumer is irm_gemm_presplit_res_f16x3_f32.  W % 16 == 0;
+ *   ch = gate channels per workgroup (8 / 16 / 32, 0 = by row length).
+ * irm_gemm_presplit_res_f16x3_f32: y = res + bias + out_scale * (W' gs), K = 32 KS streamed (project_out + the block's
+ *   residual, restormer.py:86, 92, 148); wps [ceil(M/16)][KS][hi | lo][64 lanes][8 halves] (W s_w, columns zero padded to
+ *   32 KS, split by the host), out_scale = 1 / (s_w scale).  M <= 384, KS % 4 == 0, N % 16 == 0; y may alias res.
+ *   wg_shape: 0 = default; M <= 192: 42 / 82, M <= 384: 41 / 81 (10 x waves + pixel tiles per wave). */
+int irm_dwconv3x3_gate_split_f16(const float* x, long x_bs, const float* w, const float* bias, void* gs, float scale,
+                                 int B, int hid, int H, int W, int ch, irm_stream_t stream);
+int irm_gemm_presplit_res_f16x3_f32(const void* wps, const void* xs, float* y, long y_bs, const float* res, long r_bs,
+                                    const float* bias, float out_scale, int B, int M, int KS, int N, int wg_shape,
+                                    irm_stream_t stream);
+
 /* Depth-wise 3x3 convolution, zero pad 1: y[b][c] = act(dw3x3(x[b][c]; w[c]) + bias[c]).
  * Replaces Attention.qkv_dwconv (restormer.py:106) and MaIR's conv2d+SiLU.
  * w: [C][9] (device), bias: [C] or NULL. */

@@ -298,6 +298,64 @@ def test_gemm_presplit(dev, M, K, H, W, B, ln, bias, ct, mgroups, wg_shape):
     assert torch.equal(y2, y16)
 
 
+GS_CASES = [   # M, hid, H, W, B, bias, wg_shape, ch
+    (192, 510, 8, 32, 2, True, 0, 0), (192, 510, 16, 64, 1, False, 82, 0), (384, 1021, 8, 32, 1, True, 0, 8),
+    (384, 1021, 5, 32, 3, False, 81, 16), (144, 120, 3, 32, 1, True, 0, 32), (200, 128, 9, 64, 2, True, 0, 8),
+    (192, 510, 4, 128, 1, True, 42, 0), (192, 510, 9, 144, 1, False, 0, 0), (144, 120, 6, 16, 2, True, 0, 16),
+]
+
+
+@pytest.mark.parametrize("M,hid,H,W,B,bias,wg_shape,ch", GS_CASES)
+def test_gate_split_gemm_res(dev, M, hid, H, W, B, bias, wg_shape, ch):
+    """GDFN tail on pre-split operands: irm_dwconv3x3_gate_split_f16 (fragments vs float64) and
+    irm_gemm_presplit_res_f16x3_f32 in place on the residual, against float64 and against the exact kernels
+    (irm_dwconv3x3_gate_f32 + irm_gemm1x1_f32)."""
+    N = H * W
+    tag = f"gs{M}_{hid}_{H}_{W}"
+    big = rnd(tag + "x", (B, 2 * hid + 3, H, W), -1.5, 1.5)
+    x = big.to(dev)[:, 1:1 + 2 * hid]
+    w9 = rnd(tag + "w9", (2 * hid, 9), -0.5, 0.5)
+    dwb = rnd(tag + "db", (2 * hid,), -0.2, 0.2) if bias else None
+    w2 = rnd(tag + "w2", (M, hid), -0.2, 0.2)
+    pb = rnd(tag + "pb", (M,), -0.3, 0.3) if bias else None
+    r = rnd(tag + "r", (B, M, H, W))
+    d = F.conv2d(big[:, 1:1 + 2 * hid].double(), w9.double().view(2 * hid, 1, 3, 3), dwb.double() if bias else None, padding=1,
+                 groups=2 * hid)
+    gref = F.gelu(d[:, :hid]) * d[:, hid:]
+    ref = torch.einsum("mk,bkhw->bmhw", w2.double(), gref) + r.double()
+    if bias:
+        ref = ref + pb.double().view(1, M, 1, 1)
+    KS = -(-hid // 32)
+    gs = torch.full((B * 32 * KS * N + 64,), float("nan"), device=dev)
+    ops.dwconv3x3_gate_split(x, w9.to(dev), gs, bias=dwb.to(dev) if bias else None, ch=ch)
+    assert torch.isnan(gs[B * 32 * KS * N:]).all()
+    got = _unpack_presplit(gs[:B * 32 * KS * N].cpu(), B * N, 32 * KS).view(B, N, 32 * KS).permute(0, 2, 1).reshape(B, 32 * KS, H, W)
+    got = got / ops.GATE_SPLIT_SCALE
+    eg = float((got[:, :hid] - gref).abs().max())
+    assert eg <= 4e-7 * float(gref.abs().max()) + 2e-7
+    if hid % 32:
+        assert float(got[:, hid:].abs().max()) == 0.0           # padded channels are zero
+    frag, s_w = _hip.pack_gemm_weight_presplit(w2.to(dev), k_pad=32 * KS)
+    ybig = torch.full((B, M + 4, H, W), 3.0, device=dev)
+    y = ybig[:, 2:2 + M]
+    y.copy_(r.to(dev))
+    ops.gemm_presplit_res(frag, gs, y, M, KS, out_scale=1.0 / (s_w * ops.GATE_SPLIT_SCALE), res=y,
+                          bias=pb.to(dev) if bias else None, wg_shape=wg_shape)
+    assert (ybig[:, :2] == 3.0).all() and (ybig[:, 2 + M:] == 3.0).all()
+    g32 = torch.empty(B, hid, H, W, device=dev)
+    ops.dwconv3x3_gate(x, w9.to(dev), g32, bias=dwb.to(dev) if bias else None)
+    y32 = r.clone().to(dev)
+    ops.gemm1x1(_hip.pack_gemm_weight(w2).to(dev), g32, y32, M, hid, res=y32, bias=pb.to(dev) if bias else None)
+    e16, e32 = float((y.cpu().double() - ref).abs().max()), float((y32.cpu().double() - ref).abs().max())
+    print(f"gate-split + presplit-res M{M} hid{hid} N{N} B{B}: fragments {eg:.2e}; max-abs vs float64 f16x3 {e16:.3e}  f32 {e32:.3e}")
+    # (+ 1e-6: the gated activations are split after a FIXED 2^-4 scaling - absolute floor, DESIGN.md precision section)
+    assert e16 < 4e-5 and e16 <= 2.0 * max(e32, 2e-7) + 1e-6
+    y2 = r.clone().to(dev)
+    ops.gemm_presplit_res(frag, gs, y2, M, KS, out_scale=1.0 / (s_w * ops.GATE_SPLIT_SCALE), res=y2,
+                          bias=pb.to(dev) if bias else None, wg_shape=wg_shape)
+    assert torch.equal(y2, y)
+
+
 def test_gemm_presplit_trained_like(dev):
     """Trained-like statistics: LayerNorm gains up to 30, weights spanning 1e-5 ... 10, activations x 1e-4 / 1 / 1e4 -
     power-of-two scales on both operands keep the emulation within 2x of the exact-f32 kernel pair."""
