@@ -26,6 +26,7 @@ SIGNATURES = {
     "irm_gemm1x1_f32": [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P],
     "irm_gemm1x1_f16x3_f32": [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P],
     "irm_ln_split_f16": [_P, _L, _P, _P, _I, _F, _F, _P, _I, _I, _I, _P],
+    "irm_ln_gemm_presplit_f16x3_f32": [_P, _P, _L, _P, _P, _I, _F, _F, _P, _L, _P, _F, _I, _I, _I, _I, _I, _P],
     "irm_gemm_presplit_f16x3_f32": [_P, _P, _P, _L, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "irm_dwconv3x3_gate_split_f16": [_P, _L, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
     "irm_gemm_presplit_res_f16x3_f32": [_P, _P, _P, _L, _P, _L, _P, _F, _I, _I, _I, _I, _I, _P],

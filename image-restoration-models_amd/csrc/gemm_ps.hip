@@ -24,6 +24,56 @@
 
 typedef _Float16 ps_h8 __attribute__((ext_vector_type(8)));
 
+// LayerNorm + power-of-two scale + fp16 hi/lo split of ONE pixel's channels as lane (i, g) of a wave holds them (channels
+// 32 ks + 8 g + e; the other three lanes of the pixel are 16, 32, 48 lanes away).  Every operation is an explicitly rounded
+// intrinsic (no fma contraction left to the compiler): ln_split_kernel and the LN-fused GEMM run this same function.  lw / lb: LDS, LayerNorm weight / bias x operand scale.
+template <int KS>
+__device__ __forceinline__ void ps_ln_pixel(const float (&v)[KS][8], int K, int g, const float* lw, const float* lb, int ln_mode,
+                                            float eps, ps_h8 (&hi)[KS], ps_h8 (&lo)[KS]) {
+    float s = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = __fadd_rn(s, (ks * 32 + 8 * g + e < K) ? v[ks][e] : 0.0f);
+    s = __fadd_rn(s, __shfl_xor(s, 16));
+    s = __fadd_rn(s, __shfl_xor(s, 32));
+    const float mean = __fdiv_rn(s, (float)K);
+    float q = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = __fsub_rn(v[ks][e], mean);
+            q = __fadd_rn(q, (ks * 32 + 8 * g + e < K) ? __fmul_rn(d, d) : 0.0f);
+        }
+    q = __fadd_rn(q, __shfl_xor(q, 16));
+    q = __fadd_rn(q, __shfl_xor(q, 32));
+    const float rstd = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(__fdiv_rn(q, (float)K), eps)));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const float4 w0 = *reinterpret_cast<const float4*>(lw + ks * 32 + 8 * g);
+        const float4 w1 = *reinterpret_cast<const float4*>(lw + ks * 32 + 8 * g + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(lb + ks * 32 + 8 * g);
+        const float4 b1 = *reinterpret_cast<const float4*>(lb + ks * 32 + 8 * g + 4);
+        const float we[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y;
+            if (ln_mode == IRM_LN_WITHBIAS) y = __fmaf_rn(__fmul_rn(__fsub_rn(v[ks][e], mean), rstd), we[e], be[e]);
+            else y = __fmul_rn(__fmul_rn(v[ks][e], rstd), we[e]);      // BiasFree: the mean only enters the variance
+            // finite for any input (the scale leaves 16x headroom over the typical bound; see _hip.ln_split_scale)
+            y = fminf(fmaxf(y, -65000.0f), 65000.0f);
+            // one opaque fp32 value: hi and lo must be derived from the SAME rounded product (a fused
+            // v_fma_mixlo_f16 would round the exact product instead and break the split on double-rounding ties)
+            asm volatile("" : "+v"(y));
+            const _Float16 hh = (_Float16)y;
+            hi[ks][e] = hh;
+            lo[ks][e] = (_Float16)(y - (float)hh);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 struct LnSplitArgs {
     const float* x; long x_bs;     // [B][K][N]
@@ -59,52 +109,13 @@ __global__ __launch_bounds__(256) void ln_split_kernel(LnSplitArgs a) {
             const int k = ks * 32 + 8 * g + e;
             v[ks][e] = xp[(long)min(k, a.K - 1) * a.N];
         }
-    // two-pass statistics over the K channels of the pixel (4 lanes hold them: i, i + 16, i + 32, i + 48)
-    float s = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += (ks * 32 + 8 * g + e < a.K) ? v[ks][e] : 0.0f;
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    const float mean = s / (float)a.K;
-    float q = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float d = v[ks][e] - mean;
-            q += (ks * 32 + 8 * g + e < a.K) ? d * d : 0.0f;
-        }
-    q += __shfl_xor(q, 16);
-    q += __shfl_xor(q, 32);
-    const float rstd = 1.0f / sqrtf(q / (float)a.K + a.eps);
+    ps_h8 hi[KS], lo[KS];
+    ps_ln_pixel<KS>(v, a.K, g, lw, lb, a.ln_mode, a.eps, hi, lo);
     _Float16* out = a.xs + (long)pt * KS * 1024 + lane * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        const float4 w0 = *reinterpret_cast<const float4*>(lw + ks * 32 + 8 * g);
-        const float4 w1 = *reinterpret_cast<const float4*>(lw + ks * 32 + 8 * g + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(lb + ks * 32 + 8 * g);
-        const float4 b1 = *reinterpret_cast<const float4*>(lb + ks * 32 + 8 * g + 4);
-        const float we[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-        const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        ps_h8 h, l;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float y;
-            if (a.ln_mode == IRM_LN_WITHBIAS) y = fmaf((v[ks][e] - mean) * rstd, we[e], be[e]);
-            else y = v[ks][e] * rstd * we[e];             // BiasFree: the mean only enters the variance
-            // finite for any input (the scale leaves 16x headroom over the typical bound; see _hip.ln_split_scale)
-            y = fminf(fmaxf(y, -65000.0f), 65000.0f);
-            // one opaque fp32 value: hi and lo must be derived from the SAME rounded product (a fused
-            // v_fma_mixlo_f16 would round the exact product instead and break the split on double-rounding ties)
-            asm volatile("" : "+v"(y));
-            const _Float16 hh = (_Float16)y;
-            h[e] = hh;
-            l[e] = (_Float16)(y - (float)hh);
-        }
-        *reinterpret_cast<ps_h8*>(out + ks * 1024) = h;
-        *reinterpret_cast<ps_h8*>(out + ks * 1024 + 512) = l;
+        *reinterpret_cast<ps_h8*>(out + ks * 1024) = hi[ks];
+        *reinterpret_cast<ps_h8*>(out + ks * 1024 + 512) = lo[ks];
     }
 }
 
@@ -137,6 +148,10 @@ struct PsArgs {
     int nblk;                      // pixel blocks (workgroups per output-tile group): ceil(npt / (NW WP))
     int mgroups, cpg;              // output-tile chunks (of CT tiles) per workgroup
     float out_scale;               // 1 / (s_w s_x)
+    // LNF kernels (LayerNorm + split inside the GEMM's operand load: xs is not used)
+    const float* x; long x_bs;     // [B][K][N] fp32
+    const float* lnw; const float* lnb;
+    int ln_mode; float eps, x_scale;
     int dbg;                       // IRM_PS_DBG (-DIRM_PROBES builds, timing only): 1 = stores to the dump page, 2 = no MFMAs, 4 = no weight DMA
 };
 
@@ -161,7 +176,10 @@ __device__ __forceinline__ void ps_wait_vmcnt() {
 // fragments of CT tiles for one k-step), CG = tiles per register group (two groups in flight: CT / CG must be even).
 // NW = waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU: while one loads its resident operands or stores a
 // chunk, the other one keeps the matrix cores busy - the phases of a single lock-stepped workgroup do not overlap).
-template <int KS, int WP, int CT, int CG, int NW>
+// LNF: the wave normalises and splits its own pixel tiles while loading them (ps_ln_pixel, the routine of ln_split_kernel)
+// instead of reading fragments: no ln_split launch, no write + read of xs.  Pays where every workgroup does it once
+// (one round, mgroups 1: the K 192 shapes).
+template <int KS, int WP, int CT, int CG, int NW, bool LNF = false>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_ps_kernel(PsArgs a) {
     constexpr int NS = 4;                          // ring depth
     constexpr int FR = 2 * CT;                     // 1 KiB fragments per stage
@@ -216,7 +234,28 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_ps_kernel(PsArgs a) {
 
     // ---- resident A operands: the wave's WP pixel tiles, all KS k-steps, hi and lo
     ps_h8 xh[KS][WP], xl[KS][WP];
-    {
+    if constexpr (LNF) {
+        float* lw = lbias + a.cpg * CT * 16;       // [2][32 KS] LayerNorm weight, bias x operand scale
+        for (int k = tid; k < KS * 32; k += NW * 64) {
+            lw[k] = a.lnw[k] * a.x_scale;
+            lw[KS * 32 + k] = a.ln_mode == IRM_LN_WITHBIAS ? a.lnb[k] * a.x_scale : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < WP; ++p) {
+            const int bi = pt_idx[p] / ptl;
+            const float* xp = a.x + (long)bi * a.x_bs + (pt_idx[p] - bi * ptl) * 16 + r;
+            float v[KS][8];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[ks][e] = xp[(long)(ks * 32 + 8 * g + e) * a.N];
+            ps_h8 hi[KS], lo[KS];
+            ps_ln_pixel<KS>(v, KS * 32, g, lw, lw + KS * 32, a.ln_mode, a.eps, hi, lo);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { xh[ks][p] = hi[ks]; xl[ks][p] = lo[ks]; }
+        }
+    } else {
 #pragma unroll
         for (int p = 0; p < WP; ++p) {
             const _Float16* xp = a.xs + (long)pt_idx[p] * KS * 1024 + lane * 8;
@@ -351,12 +390,12 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_ps_kernel(PsArgs a) {
     ps_wait_vmcnt<0>();                            // no LDS-DMA may be in flight when the workgroup's LDS is released
 }
 
-template <int KS, int WP, int CT, int CG, int NW>
+template <int KS, int WP, int CT, int CG, int NW, bool LNF = false>
 static int ps_launch(PsArgs a, hipStream_t stream) {
     a.nblk = (a.npt + NW * WP - 1) / (NW * WP);
-    const size_t lds = (size_t)4 * 2 * CT * 1024 + (size_t)a.cpg * CT * 64;
-    IRM_ALLOW_BIG_LDS((&gemm_ps_kernel<KS, WP, CT, CG, NW>));
-    hipLaunchKernelGGL((gemm_ps_kernel<KS, WP, CT, CG, NW>), dim3(a.nblk * a.mgroups), dim3(NW * 64), lds, stream, a);
+    const size_t lds = (size_t)4 * 2 * CT * 1024 + (size_t)a.cpg * CT * 64 + (LNF ? (size_t)KS * 256 : 0);
+    IRM_ALLOW_BIG_LDS((&gemm_ps_kernel<KS, WP, CT, CG, NW, LNF>));
+    hipLaunchKernelGGL((gemm_ps_kernel<KS, WP, CT, CG, NW, LNF>), dim3(a.nblk * a.mgroups), dim3(NW * 64), lds, stream, a);
     return irm_launch_status();
 }
 
@@ -382,6 +421,7 @@ extern "C" int irm_gemm_presplit_f16x3_f32(const void* wps, const void* xs, floa
     a.mgroups = mgroups; a.cpg = (nchunks + mgroups - 1) / mgroups;
     if ((long)(mgroups - 1) * a.cpg >= nchunks) return IRM_EINVAL;          // an empty group
     a.out_scale = out_scale; a.dbg = irm_probe_int("IRM_PS_DBG", 0);
+    a.x = nullptr; a.x_bs = 0; a.lnw = nullptr; a.lnb = nullptr; a.ln_mode = 0; a.eps = 0.0f; a.x_scale = 1.0f;
     if (K == 192) {
         if (wg_shape == 42 && ct == 8) return ps_launch<6, 2, 8, 4, 4>(a, stream);
         if (wg_shape == 42 && ct == 6) return ps_launch<6, 2, 6, 3, 4>(a, stream);
@@ -395,6 +435,27 @@ extern "C" int irm_gemm_presplit_f16x3_f32(const void* wps, const void* xs, floa
     if (wg_shape == 81 && ct == 8) return ps_launch<12, 1, 8, 4, 8>(a, stream);
     if (wg_shape == 81 && ct == 6) return ps_launch<12, 1, 6, 3, 8>(a, stream);
     return IRM_EINVAL;
+}
+
+// LayerNorm + 1x1 conv in ONE launch for K = 192 (4 waves x 3 pixel tiles, ct 4): irm_ln_split_f16's arithmetic inside the
+// operand load of irm_gemm_presplit_f16x3_f32 - no xs tensor (results agree with the pair to a few fp32 ulps).  x [B][192][N] fp32, N % 16 == 0.
+extern "C" int irm_ln_gemm_presplit_f16x3_f32(const void* wps, const float* x, long x_bs, const float* lnw, const float* lnb,
+                                              int ln_mode, float x_scale, float eps, float* y, long y_bs, const float* bias,
+                                              float out_scale, int B, int M, int K, int N, int mgroups, hipStream_t stream) {
+    if (!wps || !x || !lnw || !y || B <= 0 || M <= 0 || N <= 0 || mgroups <= 0 || K != 192) return IRM_EINVAL;
+    if (ln_mode != IRM_LN_WITHBIAS && ln_mode != IRM_LN_BIASFREE) return IRM_EINVAL;
+    if (ln_mode == IRM_LN_WITHBIAS && !lnb) return IRM_EINVAL;
+    if ((N & 15) || (y_bs & 3) || !irm_aligned16(y) || !irm_aligned16(wps) || !(x_scale > 0.0f)) return IRM_EINVAL;
+    PsArgs a;
+    a.xs = nullptr; a.wps = reinterpret_cast<const _Float16*>(wps); a.bias = bias;
+    a.y = y; a.y_bs = y_bs; a.M = M; a.N = N; a.mtiles = (M + 15) / 16;
+    a.npt = (int)((long)B * N / 16); a.nblk = 0;
+    const int nchunks = (a.mtiles + 3) / 4;
+    a.mgroups = mgroups; a.cpg = (nchunks + mgroups - 1) / mgroups;
+    if ((long)(mgroups - 1) * a.cpg >= nchunks) return IRM_EINVAL;
+    a.out_scale = out_scale; a.dbg = 0;
+    a.x = x; a.x_bs = x_bs; a.lnw = lnw; a.lnb = lnb; a.ln_mode = ln_mode; a.eps = eps; a.x_scale = x_scale;
+    return ps_launch<6, 3, 4, 2, 4, true>(a, stream);
 }
 
 // ===============================================================================================================

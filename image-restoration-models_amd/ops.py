@@ -168,6 +168,24 @@ def gemm_presplit(wps: torch.Tensor, xs: torch.Tensor, y: torch.Tensor, M: int, 
             int(mgroups), int(wg_shape), tag=f"M{M} K{K} N{N} B{B} ct{ct} mg{mgroups}")
 
 
+def ln_gemm_presplit(wps, x, y, M: int, K: int, lnw, lnb, ln_mode: int, x_scale: float, *, out_scale: float, bias=None,
+                     xs=None, eps: float = 1e-5):
+    """y = W LN(x) + bias on the pre-split path.  K = 192 and a plan with ONE workgroup per pixel block: one launch
+    (irm_ln_gemm_presplit_f16x3_f32, LayerNorm + split inside the GEMM's operand load - the pair's arithmetic);
+    otherwise ln_split into `xs` + gemm_presplit."""
+    _chk(x, "x"), _chk(y, "y")
+    B, _, H, W = x.shape
+    N = H * W
+    ct, mgroups, shape = _hip.plan_presplit((M + 15) // 16, B * N // 16, K)
+    if K == 192 and mgroups == 1 and not os.environ.get("IRM_NO_LN_FUSE"):
+        _launch("gemm_ps_f16x3", 2.0 * B * M * K * N, 4.0 * B * N * (K + M), "irm_ln_gemm_presplit_f16x3_f32", _hip.ptr(wps),
+                _hip.ptr(x), _bs(x), _hip.ptr(lnw), _hip.ptr(lnb), int(ln_mode), float(x_scale), float(eps), _hip.ptr(y), _bs(y),
+                _hip.ptr(bias), float(out_scale), B, M, K, N, 1, tag=f"M{M} K{K} N{N} B{B} ln-fused")
+        return
+    ln_split(x, xs, lnw, lnb, ln_mode, x_scale, eps)
+    gemm_presplit(wps, xs, y, M, K, out_scale=out_scale, bias=bias, ct=ct, mgroups=mgroups, wg_shape=shape)
+
+
 GATE_SPLIT_SCALE = 0.0625      # 2^-4: gated activations up to ~1e6 stay inside fp16 (as irm_gemm1x1_f16x3_f32 without LN)
 
 

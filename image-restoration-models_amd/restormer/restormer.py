@@ -280,8 +280,8 @@ class Restormer(nn.Module):
             # LayerNorm + fp16 hi/lo split once (statistics in the kernel), then a pure matrix-core GEMM
             xs = self._buf("xsplit", B * C * N, dev)
             frag, out_scale, s_x = w["qkv_ps"]
-            ops.ln_split(x, xs, w["n1w"], w["n1b"], blk.norm1.mode, s_x)
-            ops.gemm_presplit(frag, xs, qkv, 3 * C, C, out_scale=out_scale, bias=w["qkv_b"])
+            ops.ln_gemm_presplit(frag, x, qkv, 3 * C, C, w["n1w"], w["n1b"], blk.norm1.mode, s_x, out_scale=out_scale,
+                                 bias=w["qkv_b"], xs=xs)
         else:
             if not have_stats:
                 ops.ln_stats(x, stats)
@@ -317,8 +317,8 @@ class Restormer(nn.Module):
         g = big_b[:B * hid * N].view(B, hid, H, W)
         if presplit:
             frag, out_scale, s_x = w["pin_ps"]
-            ops.ln_split(x, xs, w["n2w"], w["n2b"], blk.norm2.mode, s_x)
-            ops.gemm_presplit(frag, xs, h, 2 * hid, C, out_scale=out_scale, bias=w["pin_b"])
+            ops.ln_gemm_presplit(frag, x, h, 2 * hid, C, w["n2w"], w["n2b"], blk.norm2.mode, s_x, out_scale=out_scale,
+                                 bias=w["pin_b"], xs=xs)
         else:
             if not fuse:
                 ops.ln_stats(x, stats)

@@ -109,6 +109,11 @@ int irm_gemm1x1_f16x3_f32(const float* wp_split, long w_bs, const float* x, long
  *   ct output tiles per pass; mgroups: workgroups sharing the output tiles of a pixel block (no empty group);
  *   wg_shape = 10 x waves per workgroup + pixel tiles per wave: K 192: 42 or 32 (ct 6 / 8), 43 (ct 4); K 384: 81
  *   (ct 6 / 8); 0 = default.  N % 16 == 0 (pixel tiles are numbered through the batch); act must be 0. */
+/* irm_ln_split_f16 + irm_gemm_presplit_f16x3_f32 in one launch for K = 192 (same arithmetic): every wave normalises
+ * and splits its own pixel tiles while loading them; mgroups as above (1 where the launch is a single round). */
+int irm_ln_gemm_presplit_f16x3_f32(const void* wps, const float* x, long x_bs, const float* lnw, const float* lnb, int ln_mode,
+                                   float x_scale, float eps, float* y, long y_bs, const float* bias, float out_scale, int B,
+                                   int M, int K, int N, int mgroups, irm_stream_t stream);
 int irm_ln_split_f16(const float* x, long x_bs, const float* lnw, const float* lnb, int ln_mode, float scale, float eps,
                      void* xs, int B, int K, int N, irm_stream_t stream);
 int irm_gemm_presplit_f16x3_f32(const void* wps, const void* xs, float* y, long y_bs, const float* bias, float out_scale,

@@ -356,6 +356,44 @@ def test_gate_split_gemm_res(dev, M, hid, H, W, B, bias, wg_shape, ch):
     assert torch.equal(y2, y)
 
 
+@pytest.mark.parametrize("M,H,W,B,ln,bias", [(576, 16, 16, 2, 1, True), (1020, 12, 12, 3, 2, False), (300, 4, 4, 1, 1, True),
+                                             (1020, 32, 32, 6, 1, True)])
+def test_ln_gemm_presplit_fused(dev, M, H, W, B, ln, bias):
+    """irm_ln_gemm_presplit_f16x3_f32 (LayerNorm + split inside the GEMM's operand load, K = 192) against float64 and against
+    the two-launch pair irm_ln_split_f16 + irm_gemm_presplit_f16x3_f32 (same arithmetic; the two agree to a few fp32 ulps
+    and are equally close to float64), incl. tail workgroups and a sentinel-padded output."""
+    K, N = 192, H * W
+    big = rnd(f"lfx{M}{H}", (B, K + 2, H, W), -2, 3)
+    x = big.to(dev)[:, 1:1 + K]
+    w = rnd(f"lfw{M}", (M, K), -0.3, 0.3)
+    lnw_c = rnd(f"lflw{M}", (K,), 0.5, 1.5)
+    lnb_c = rnd(f"lflb{M}", (K,), -0.2, 0.2) if ln == 1 else None
+    bv_c = rnd(f"lfb{M}", (M,), -0.3, 0.3) if bias else None
+    lnw, lnb, bv = lnw_c.to(dev), None if lnb_c is None else lnb_c.to(dev), None if bv_c is None else bv_c.to(dev)
+    ref = torch.einsum("mk,bkhw->bmhw", w.double(), _ln_ref(big[:, 1:1 + K].double(), lnw_c, lnb_c, ln))
+    if bias:
+        ref = ref + bv_c.double().view(1, M, 1, 1)
+    frag, s_w = _hip.pack_gemm_weight_presplit(w.to(dev))
+    s_x = _hip.ln_split_scale(lnw, lnb, K, ln == 1)
+    xs = torch.empty(B * K * N, device=dev)
+    ops.ln_split(x, xs, lnw, lnb, ln, s_x)
+    y0 = torch.empty(B, M, H, W, device=dev)
+    ops.gemm_presplit(frag, xs, y0, M, K, out_scale=1.0 / (s_w * s_x), bias=bv, ct=4, mgroups=1, wg_shape=43)
+    y1 = torch.full((B, M + 2, H, W), 9.0, device=dev)
+    _hip.call("irm_ln_gemm_presplit_f16x3_f32", _hip.ptr(frag), _hip.ptr(x), x.stride(0), _hip.ptr(lnw), _hip.ptr(lnb), ln,
+              float(s_x), 1e-5, _hip.ptr(y1[:, 1:1 + M]), y1.stride(0), _hip.ptr(bv), float(1.0 / (s_w * s_x)), B, M, K, N, 1)
+    assert (y1[:, 0] == 9.0).all() and (y1[:, -1] == 9.0).all()
+    e0 = float((y0.cpu().double() - ref).abs().max())
+    e1 = float((y1[:, 1:1 + M].cpu().double() - ref).abs().max())
+    dd = float((y1[:, 1:1 + M] - y0).abs().max())
+    print(f"LN-fused presplit M{M} N{N} B{B} ln{ln}: vs float64 fused {e1:.3e}, pair {e0:.3e}; fused vs pair {dd:.3e}")
+    assert e1 < 2e-5 and e1 <= 1.5 * e0 + 1e-6 and dd <= 1e-5
+    y2 = torch.empty(B, M, H, W, device=dev)
+    _hip.call("irm_ln_gemm_presplit_f16x3_f32", _hip.ptr(frag), _hip.ptr(x), x.stride(0), _hip.ptr(lnw), _hip.ptr(lnb), ln,
+              float(s_x), 1e-5, _hip.ptr(y2), y2.stride(0), _hip.ptr(bv), float(1.0 / (s_w * s_x)), B, M, K, N, 1)
+    assert torch.equal(y2, y1[:, 1:1 + M])                        # run-to-run bit identity
+
+
 def test_gemm_presplit_trained_like(dev):
     """Trained-like statistics: LayerNorm gains up to 30, weights spanning 1e-5 ... 10, activations x 1e-4 / 1 / 1e4 -
     power-of-two scales on both operands keep the emulation within 2x of the exact-f32 kernel pair."""

@@ -41,6 +41,12 @@ for (M, K, H, W) in [(1020, 192, 128, 128), (576, 192, 128, 128), (2042, 384, 64
     t_split = timeit(lambda: ops.ln_split(x, xs, lnw, lnb, 1, s_x))
     kw = {}
     t_new = timeit(lambda: ops.gemm_presplit(frag, xs, y2, M, K, out_scale=1.0 / (s_w * s_x), **kw))
+    t_fused = None
+    if K == 192:
+        t_fused = timeit(lambda: _hip.call("irm_ln_gemm_presplit_f16x3_f32", _hip.ptr(frag), _hip.ptr(x), x.stride(0), _hip.ptr(lnw),
+                                           _hip.ptr(lnb), 1, float(s_x), 1e-5, _hip.ptr(y2), y2.stride(0), None,
+                                           float(1.0 / (s_w * s_x)), B, M, K, N, 1))
+        print(f"   LN fused into the GEMM: {t_fused:6.1f} us")
     err = float((y - y2).abs().max())
     gb = 4.0 * B * N * (K + M) / 1e3
     print(f"M{M} K{K} {H}x{W}: ln_stats {t_stats:6.1f} + gemm {t_old:6.1f} = {t_stats + t_old:6.1f} us | ln_split {t_split:6.1f} "
