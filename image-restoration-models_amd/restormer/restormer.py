@@ -325,11 +325,11 @@ class Restormer(nn.Module):
             ops.gemm1x1(w["pin_s" if s_pin else "pin"], x, h, 2 * hid, C, bias=w["pin_b"], stats=stats, lnw=w["n2w"],
                         lnb=w["n2b"], ln_mode=blk.norm2.mode, split=s_pin)
         emit = fuse and want_stats
-        if (split and "pout_ps" in w and not emit and ops.can_gate_split(C, hid, W, N) and C > 192
-                and not os.environ.get("IRM_NO_GATE_SPLIT")):
-            # gate -> fp16 hi/lo fragments (the bytes of g), then a K-streamed matrix-core GEMM in place on x.  Only at
-            # C = 384 (6 x 64^2 in the model: 87 + 85 us against 65 + 126 us); at C = 192 the fragment-writing gate kernel
-            # loses more (174 vs 138 us) than the GEMM gains (107 vs 116 us)
+        if (split and "pout_ps" in w and not emit and ops.can_gate_split(C, hid, W, N) and os.environ.get("IRM_GATE_SPLIT")):
+            # gate -> fp16 hi/lo fragments (the bytes of g), then a K-streamed matrix-core GEMM in place on x.  OPT-IN
+            # (IRM_GATE_SPLIT=1): the GEMM gains (C = 384: 85 vs 126 us, C = 192: 107 vs 116 us in the model) but the
+            # fragment-writing gate kernel loses more (87 vs 65 us, 174 vs 138 us); same-box A/B of the whole step:
+            # 54.37 ms without, 54.65 ms with it at C = 384
             frag, out_scale = w["pout_ps"]
             ks = -(-hid // 32)
             gs = self._buf("gsplit", B * 32 * ks * N, dev)
