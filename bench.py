@@ -324,6 +324,21 @@ def main():
                                "launches": g["launches"],
                                "avg_launch_us": g["ms"] * 1e3 / g["launches"],
                                "share_of_kernel_time": g["ms"] / tot_ms}
+            if dom == "gdfn_fused":
+                # second view, clearly separate from `achieved`: SURVEY 8(d) counts the bytes at the REFERENCE's op
+                # boundaries; the rows this one kernel replaces are LN + project_in (1 + 2r), dwconv + gate (3r) and
+                # project_out + residual (r + 2) tensors of C N floats, r = hid / C = 255 / 96 (127 / 48 at C = 48): (3 + 6r) / 2 x its
+                # own 2 C N boundary.  The kernel's own boundary traffic is `achieved`'s basis under bound "hbm" only.
+                r_ = 255.0 / 96.0
+                ref_bytes = g["bytes"] / 2.0 * (3.0 + 6.0 * r_)       # own boundary (timer): x read (also the residual) + y written = 2 C N
+                out["roofline"]["reference_rows"] = {
+                    "rows": "R1 LayerNorm + R2 project_in + R3 depth-wise 3x3 + R5 gate + R2 project_out + residual (SURVEY 8a)",
+                    "survey_bytes_per_launch": ref_bytes / g["launches"],
+                    "gbs": ref_bytes / (g["ms"] * 1e-3) / 1e9,
+                    "frac_of_hbm_peak": ref_bytes / (g["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                    "note": "bytes the reference's op-by-op decomposition moves for the rows this kernel fuses (SURVEY 8d: "
+                            "18.9 C N floats per GDFN branch) / this kernel's time: what the fusion is worth in the survey's "
+                            "own unit; the kernel itself moves 2 C N floats (+ halo) and is bound by its matrix + vector + LDS pipes"}
             out["kernels"] = {
                 k: {"launches": v["launches"], "ms_per_step": v["ms"] / args.steps,
                     "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12, "gbs": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
