@@ -399,3 +399,35 @@ def test_split_range_guard_falls_back_per_layer():
     pk = m._pack()
     assert "qkv_s" not in pk["latent.0"] and "pout_s" not in pk["latent.0"] and "pin_s" in pk["latent.0"]
     assert "qkv_s" in pk["encoder_level3.0"] and "pout_s" in pk["encoder_level3.0"]
+
+
+def test_presplit_host_side_packing_and_plans():
+    """Host side of the pre-split GEMM path (gemm_ps.hip): fragment packing round trip (incl. zero K padding), the
+    power-of-two scales, and launch plans without empty workgroup groups."""
+    w = gin("psw", (570, 192), -0.3, 0.3)
+    frag, s_w = _hip.pack_gemm_weight_presplit(w)
+    assert np.log2(s_w) == int(np.log2(s_w)) and 2.0 ** 13 <= float(w.abs().max()) * s_w < 2.0 ** 14
+    h = frag.view(torch.float16).double().view(-1, 6, 2, 4, 16, 8)                 # [tile][ks][hi|lo][g][m][e]
+    back = (h[:, :, 0] + h[:, :, 1]).permute(0, 3, 1, 2, 4).reshape(-1, 192)
+    assert back.shape[0] == 576 and float(back[570:].abs().max()) == 0.0         # rows beyond M are zero
+    assert float((back[:570] / s_w - w.double()).abs().max()) <= 2.0 ** -21 * float(w.abs().max())
+    w2 = gin("psw2", (192, 510), -0.2, 0.2)
+    frag2, s2 = _hip.pack_gemm_weight_presplit(w2, k_pad=512)
+    h2 = frag2.view(torch.float16).double().view(-1, 16, 2, 4, 16, 8)
+    back2 = (h2[:, :, 0] + h2[:, :, 1]).permute(0, 3, 1, 2, 4).reshape(-1, 512)
+    assert float(back2[:, 510:].abs().max()) == 0.0
+    assert float((back2[:192, :510] / s2 - w2.double()).abs().max()) <= 2.0 ** -21 * float(w2.abs().max())
+    # operand scale of the LayerNorm output: the static bound stays inside fp16 for any gain
+    for gain, bias in ((1.0, 0.1), (30.0, 2.0), (1e-3, 0.0), (1e4, 50.0)):
+        lnw, lnb = torch.full((192,), gain), torch.full((192,), bias)
+        s = _hip.ln_split_scale(lnw, lnb, 192, True)
+        assert np.log2(s) == int(np.log2(s)) and (gain * 191 ** 0.5 + bias) * s < 2.0 ** 15
+        assert _hip.ln_split_scale(lnw, None, 192, False) == _hip.ln_split_scale(lnw, None, 192, True) / 16.0
+    for mtiles in (1, 9, 36, 64, 72, 128):
+        for npt in (1, 16, 576, 1536, 2304, 6144):
+            for K in (192, 384):
+                ct, mg, shape = _hip.plan_presplit(mtiles, npt, K)
+                chunks = -(-mtiles // ct)
+                assert ct in (4, 6, 8) and 1 <= mg <= chunks and (mg - 1) * -(-chunks // mg) < chunks
+                assert shape == (43 if K == 192 else 81)
+    assert _hip.plan_presplit(64, 6144, 192) == (4, 1, 43) and _hip.plan_presplit(128, 1536, 384) == (8, 4, 81)
