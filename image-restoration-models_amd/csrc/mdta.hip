@@ -165,8 +165,17 @@ __global__ __launch_bounds__(256, 2) void mdta_gram_ring_kernel(GramArgs a) {
     const int i = lane & 15, kk = lane >> 4;
     const int b = blockIdx.y;
     const int head = blockIdx.x / a.nchunk, chunk_id = blockIdx.x % a.nchunk;
+#ifdef GRAM_CONTIGUOUS_CHUNKS
     const int nbeg = chunk_id * a.chunk;
     const int S = (min(nbeg + a.chunk, a.N) - nbeg) / BP;
+    const long sstep = BP;
+#else
+    // interleaved pixel blocks (see mdta_gram_f16x3_kernel): workgroup j takes the BP-pixel blocks j, j + nchunk, ...
+    const int nbeg = chunk_id * BP;
+    const int nblocks = a.N / BP;
+    const int S = chunk_id < nblocks ? (nblocks - chunk_id + a.nchunk - 1) / a.nchunk : 0;
+    const long sstep = (long)a.nchunk * BP;
+#endif
     const float* base = a.qkv + (long)b * a.bs + nbeg;
 
     // DMA sources of this lane: instruction j of this wave covers rows RPB*(4j + wave) ..; lane = rr*CPR + p
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void mdta_gram_ring_kernel(GramArgs a) {
         float* dst = smem + (s % NS) * STG + wave * 256;
 #pragma unroll
         for (int j = 0; j < LPS; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long)s * BP),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + s * sstep),
                                              (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
         }
     };
@@ -316,8 +325,21 @@ __global__ __launch_bounds__(256, 2) void mdta_gram_f16x3_kernel(GramArgs a, con
     const int i = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
     const int head = blockIdx.x / a.nchunk, chunk_id = blockIdx.x % a.nchunk;
+#ifdef GRAM_CONTIGUOUS_CHUNKS
     const int nbeg = chunk_id * a.chunk;
     const int S = (min(nbeg + a.chunk, a.N) - nbeg) / BP;
+    const long sstep = BP;
+#else
+    // INTERLEAVED pixel blocks: workgroup j of an (image, head) takes the BP-pixel blocks j, j + nchunk, j + 2 nchunk, ...
+    // The nchunk workgroups run side by side and advance together: at any moment they read ONE contiguous run of
+    // nchunk x BP pixels of every channel row (10 KiB instead of nchunk runs of 128 bytes, 12 KiB apart) - DRAM pages
+    // are used whole.  The partial records cover other pixel sets than with contiguous chunks; their fixed-order sum
+    // is the same Gram matrix.
+    const int nbeg = chunk_id * BP;
+    const int nblocks = a.N / BP;
+    const int S = chunk_id < nblocks ? (nblocks - chunk_id + a.nchunk - 1) / a.nchunk : 0;
+    const long sstep = (long)a.nchunk * BP;
+#endif
     const float* base = a.qkv + (long)b * a.bs + nbeg;
 
     const float* src[LPS];
@@ -332,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void mdta_gram_f16x3_kernel(GramArgs a, con
         float* dst = smem + (s % NS) * STG + wave * 256;
 #pragma unroll
         for (int j = 0; j < LPS; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long)s * BP),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + s * sstep),
                                              (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
         }
     };
