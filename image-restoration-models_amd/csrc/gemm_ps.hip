@@ -272,8 +272,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_ps_kernel(PsArgs a) {
     // one or two L2 channels per XCD serving everybody - instead of spreading their reads over the whole matrix.
 #ifdef PS_NO_ROTATE
     const int rot = 0;
-#else
+#elif defined(PS_ROTATE_PER_WG)
     const int rot = pb % nc;
+#else
+    // per XCD, not per workgroup: the workgroups of an XCD (neighbouring pixel blocks) keep one chunk order, so that
+    // together they write long contiguous runs of every output row and share each weight line through their L2; the
+    // eight XCDs start an eighth of the matrix apart
+    const int rot = (a.nblk & 7) == 0 ? (int)(((long)(pb / (a.nblk >> 3)) * nc) >> 3) : pb % nc;
 #endif
     auto cm = [&](int c) { const int cc = c + rot; return c0 + (cc >= nc ? cc - nc : cc); };
 
