@@ -141,6 +141,40 @@ def cpu_baseline(model, frame_u8, gpu_tile, tile_edge):
     return out
 
 
+def psnr_parity(frame0, target_u8):
+    """PSNR parity of frame 0 against the REFERENCE's CPU path (north_star: within 0.01 dB): psnr_cpu is the PSNR of
+    the reference's own run_model_inference output for this frame (src/utils.py:353-454 with the reference Restormer
+    on the CPU, 134 s on 8 cores, generated once by oracle/gen_golden.py --only fullsize_frame and committed as
+    tests/golden/restormer_fullsize_frame.npz - data, not code); psnr_gpu is this run's frame."""
+    path = os.path.join(ROOT, "tests", "golden", "restormer_fullsize_frame.npz")
+    if frame0 is None or not os.path.exists(path):
+        return {"psnr_cpu": None, "psnr_gpu": None, "abs_dpsnr": None}
+    g = np.load(path)
+    out_u8 = frame0[0].cpu().numpy()
+    mse = float(np.mean((out_u8.astype(np.float64) - target_u8.astype(np.float64)) ** 2))
+    psnr_gpu = float(10 * np.log10(255.0 ** 2 / max(mse, 1e-12)))
+    diff = np.abs(out_u8.astype(np.int32) - g["pred_u8"].astype(np.int32))
+    return {"psnr_cpu": float(g["psnr"]), "psnr_gpu": psnr_gpu, "abs_dpsnr": abs(psnr_gpu - float(g["psnr"])),
+            "frame0_u8_bytes_differing_from_cpu_reference": int((diff > 0).sum()), "frame0_u8_max_diff": int(diff.max()),
+            "psnr_parity_source": "frame 0 (rank 0); CPU side = the reference's run_model_inference + reference Restormer "
+                                  "(tests/golden/restormer_fullsize_frame.npz, oracle/gen_golden.py --only fullsize_frame)"}
+
+
+def pmc_step_totals():
+    """(HBM bytes per frame, frames) over the irm kernels of the committed PMC passes, or (None, None)."""
+    try:
+        with open(PMC_FILE) as f:
+            d = json.load(f)
+    except OSError:
+        return None, None
+    frames = d.get("_frames") or sum(v["launches"] for k, v in d.items() if k.startswith("blend_kernel"))
+    if not frames:
+        return None, None
+    tot = sum(v["launches"] * v["hbm_bytes_per_launch"] for k, v in d.items()
+              if not k.startswith("_") and v.get("hbm_bytes_per_launch") is not None)
+    return tot / frames, frames
+
+
 #: timer group -> (kernel label, roofline that bounds it, regex of its instantiations in the PMC table)
 ROOFLINE_KERNELS = {
     "gdfn_fused": ("lnpw_dw_fused_kernel<GATE> (irm_gdfn_fused_f16x3_f32: LayerNorm + project_in + depth-wise 3x3 + GELU gate + "
@@ -180,7 +214,8 @@ def pmc_traffic(pattern):
     return sum(v["launches"] * v["hbm_bytes_per_launch"] for v in rows) / n if n else None
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r02", "final_pmc_traffic.json")
+PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", r, "final_pmc_traffic.json") for r in ("r03", "r02"))
+                 if os.path.exists(p)), os.path.join(ROOT, "profiles", "r03", "final_pmc_traffic.json"))
 
 
 def pmc_provenance():
@@ -241,8 +276,11 @@ def main():
                                           max_batch=model.max_tiles_per_batch, keep_tiles=keep)
 
     keep = []
+    frame0 = None                                   # (uint8 frame, SSE) of frame 0: the PSNR-parity record below
     for i in range(args.warmup):
-        step(i, keep if i == 0 else None)
+        r = step(i, keep if i == 0 else None)
+        if i == 0:
+            frame0 = r
     torch.cuda.synchronize()
 
     timer = None if args.no_kernel_timer else ops.KernelTimer(detail=args.detail is not None)
@@ -251,7 +289,13 @@ def main():
     torch.cuda.synchronize()
     ops.TIMER = timer
     t0 = time.perf_counter()
-    results = [step(i) for i in range(args.steps)]
+    results, failed = [], []
+    for i in range(args.steps):
+        try:                                        # a frame that raises is reported, not fatal
+            results.append((i, step(i)))
+        except Exception as e:                      # noqa: BLE001
+            failed.append(rank * args.steps + i)
+            print(f"[bench] rank {rank}: frame {i} failed: {type(e).__name__}: {e}", file=sys.stderr)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -260,14 +304,17 @@ def main():
 
     # max over ranks, PSNR rows gathered once (tens of bytes per image)
     rows = [(rank * args.steps + i, float(10 * np.log10(255.0 ** 2 / max(float(s.item()) / (H * W * C), 1e-12))))
-            for i, (_, s) in enumerate(results)]
-    elapsed, table = parallel.gather_results(elapsed, rows, dev)
-    psnr = table[:, 1].numpy()
+            for i, (_, s) in results]
+    elapsed, table, failed_all = parallel.gather_results(elapsed, rows, dev, failed_ids=failed)
+    psnr = table[:, 1].numpy() if table.shape[0] else np.array([float("nan")])
+    n_done = int(table.shape[0])
+    if frame0 is None and rank == 0:                # --warmup 0: frame 0 for the parity record, outside the timed region
+        frame0 = step(0, keep)
 
     if rank == 0:
         out = {
             "metric": "images/sec + PSNR, Restormer motion-deblur 1280x720",
-            "value": world * args.steps / elapsed, "unit": "images/s",
+            "value": n_done / elapsed, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
@@ -282,7 +329,9 @@ def main():
                        "global_batch": world, "tile": cfg["patch_size"], "overlap": cfg["patch_overlap"],
                        "parallelism": f"per-image shard x{world}, no data-path collective"},
             "psnr_db_mean": float(psnr.mean()), "psnr_db_std": float(psnr.std()),
+            "failed_image_ids": failed_all,
         }
+        out.update(psnr_parity(frame0, host_frames[0][1]))
         if timer is not None:
             ks = timer.summary()
             if args.detail:
@@ -353,13 +402,26 @@ def main():
             # the bound that applies to the arithmetic actually run: with the 1x1 convs emulated on the fp16 cores the
             # f32-MFMA bound no longer binds, the reference's kernel-boundary HBM traffic does
             bound_ms = max(hbm_ms, mfma_ms) if exact else hbm_ms
+            # this build's OWN bound: the bytes its kernel boundaries still move at 8 TB/s against the
+            # matrix work it issues (three fp16 MFMA passes per fp32 product on the emulated GEMMs) at the dense fp16
+            # peak - the fraction that cannot flatter, because fused-away traffic is not counted
+            own_hbm_ms = Bt / (PEAK_HBM_GBS * 1e9) * 1e3
+            own_mfma_ms = (F / (PEAK_F32_MFMA_TFLOPS * 1e12) if exact else 3.0 * F / (PEAK_F16_MFMA_TFLOPS * 1e12)) * 1e3
+            own_bound_ms = max(own_hbm_ms, own_mfma_ms)
+            pmc_bytes, pmc_frames = pmc_step_totals()
             out["step_model"] = {
                 "reference_gbytes": REF_STEP_GBYTES, "reference_tflop": REF_STEP_TFLOP,
                 "hbm_bound_ms": hbm_ms, "f32_mfma_bound_ms": mfma_ms, "bound": "f32 mfma" if exact and mfma_ms > hbm_ms else "hbm",
                 "bound_ms": bound_ms, "frac_of_bound": bound_ms / (t_step * 1e3),
                 "this_build_kernel_boundary_gbytes": Bt / 1e9, "this_build_algorithmic_gflop": F / 1e9,
+                "own_hbm_bound_ms": own_hbm_ms, "own_mfma_bound_ms": own_mfma_ms, "own_bound_ms": own_bound_ms,
+                "own_frac": own_bound_ms / (t_step * 1e3),
+                "hbm_util": None if pmc_bytes is None else pmc_bytes / (t_step * PEAK_HBM_GBS * 1e9),
+                "hbm_gbytes_per_frame_pmc": None if pmc_bytes is None else pmc_bytes / 1e9,
                 "note": "reference_* = the reference's op-boundary decomposition (SURVEY 8d); this_build_* = what is left "
-                        "at this build's kernel boundaries after fusion (timer rows)"}
+                        "at this build's kernel boundaries after fusion (timer rows); own_* = this build's own boundary bytes / "
+                        "8 TB/s vs its issued matrix work (3 fp16 MFMA passes per emulated fp32 product) / 2.5 PFLOP/s; "
+                        "hbm_util = HBM bytes per frame measured by the committed PMC passes / (step time x 8 TB/s)"}
         if world == 1 and not args.no_legs and not os.environ.get("IRM_GEMM_EXACT"):
             # reference legs, each in its own process (the emulation switch is read when the weights are packed)
             torch.cuda.synchronize()
@@ -367,13 +429,6 @@ def main():
                            {"IRM_GEMM_EXACT": "1"})
             out["value_exact_f32"] = None if ex is None else ex["value"]
             out["value_exact_f32_note"] = "IRM_GEMM_EXACT=1: every GEMM on the f32-input MFMA, no fused branch kernels; 5 steps"
-            ts = child_leg(["--steps", str(max(args.steps, 8)), "--warmup", "2", "--no-cpu-baseline", "--no-kernel-timer",
-                            "--no-legs", "--streams", "2"], {})
-            out["value_two_streams"] = None if ts is None else ts["value"]
-            out["value_two_streams_note"] = ("model.num_streams = 2: the frame's tiles run as two groups on two HIP streams, so "
-                                             "the tails of ~600 launches overlap.  Not `value`: per-launch events of overlapping kernels "
-                                             "are not kernel durations, and overlapping forwards are not bit-reproducible run to run "
-                                             "(+-1 in <0.2 % of the output bytes; DESIGN section 6)")
             pc = child_leg(["--leg", "pcie", "--steps", "8", "--warmup", "2"], {})
             out["value_pcie_inclusive"] = None if pc is None else pc["value"]
             out["value_pcie_inclusive_note"] = ("get_model_prediction(model, numpy_frame, device, **patch_config): uint8 frame in "

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16x3_kernel(ConvF16Args a) {
                     cf_h8 hi, lo;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        float x = __fmul_rn(rp[e * CF_PLANE], 0.0625f);
+                        float x = irm_sat_h(__fmul_rn(rp[e * CF_PLANE], 0.0625f));
                         asm volatile("" : "+v"(x));                          // one rounded value for hi and lo (see fused_block.hip)
                         const _Float16 h = (_Float16)x;
                         hi[e] = h;

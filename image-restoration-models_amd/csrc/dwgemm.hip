@@ -315,7 +315,7 @@ void dwgemm_kernel(DwGemmArgs a) {
                 for (int p = 0; p < PT; ++p)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float x = ag[j][p] * 0.0625f;
+                        const float x = irm_sat_h(ag[j][p] * 0.0625f);
                         ah[p][j] = (_Float16)x;
                         al[p][j] = (_Float16)(x - (float)ah[p][j]);
                     }

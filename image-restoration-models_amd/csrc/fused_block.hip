@@ -502,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             for (int q = 0; q < (GATE ? 2 : 0); ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float gx = __fmul_rn(fb_gelu1(o[0][q][e]) * o[1][q][e], 0.0625f);
+                    float gx = irm_sat_h(__fmul_rn(fb_gelu1(o[0][q][e]) * o[1][q][e], 0.0625f));
                     asm volatile("" : "+v"(gx));         // one rounded value for hi and lo (see the input split)
                     const _Float16 h = (_Float16)gx;
                     Gh[q][4 * par + e] = h;

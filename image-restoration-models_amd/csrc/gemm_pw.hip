@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
                     if (LN == IRM_LN_WITHBIAS)
                         xv[kk] = fmaf(fmaf(x, rs[p], nmr[p]), lnp[s * BK + kk * 4 + g], lnp[KP + s * BK + kk * 4 + g]);
                     else if (LN == IRM_LN_BIASFREE) xv[kk] = x * rs[p] * lnp[s * BK + kk * 4 + g];
-                    else xv[kk] = x * 0.0625f;            // not normalised: 2^-4 keeps |x| up to 1e6 inside fp16
+                    else xv[kk] = irm_sat_h(x * 0.0625f);            // not normalised: 2^-4 keeps |x| up to 1e6 inside fp16
                 }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {

@@ -90,4 +90,10 @@ __device__ __forceinline__ void irm_st4(float* row, int n, int N, float4 v) {
     if (n + 2 < N) row[n + 2] = v.z;
     if (n + 3 < N) row[n + 3] = v.w;
 }
+// fp16 hi/lo splits behind a FIXED scale (2^-4: gated activations, v, un-normalised GEMM inputs): the scaled value is
+// saturated at +-65000 before the split, so an out-of-range activation (|x| > ~1e6) gives a clamped, finite operand instead
+// of fp16 infinities and a NaN tile (one v_med3_f32; the scaled splits behind a LayerNorm or a pack-time bound cannot
+// overflow and do not clamp).
+__device__ __forceinline__ float irm_sat_h(float x) { return __builtin_amdgcn_fmed3f(x, -65000.0f, 65000.0f); }
+
 static inline bool irm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

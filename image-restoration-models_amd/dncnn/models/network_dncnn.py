@@ -45,6 +45,9 @@ class DnCNN(nn.Module):
         self.load_state_dict(synth.synth_state_dict(shapes, seed=seed, rules=SYNTH_RULES), strict=True)
         return self
 
+    def release_workspace(self):
+        self._ws = {}
+
     @torch.no_grad()
     def forward(self, x):
         require_cuda(x, "DnCNN")

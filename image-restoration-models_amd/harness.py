@@ -24,25 +24,42 @@ def synthetic_loader(n_images: int, h: int = 720, w: int = 1280, c: int = 3, see
 
 
 def evaluate(model, loader, device, patch_config: dict, *, task: str, subtask: str, dataset: str, model_name: str,
-             sigma='N/A', need_degradation=False, noise_level=None, with_ssim=True) -> dict:
-    """One results_table row (scripts/tests.py:399-412)."""
-    psnr_list, ssim_list, time_list = [], [], []
-    for input_img, target_img, _name in loader:
-        pred, ms = get_model_prediction(model, input_img, device, **patch_config, need_degradation=need_degradation,
-                                        noise_level=noise_level)
-        if with_ssim:
-            p, s = calculate_metrics(pred, target_img)
-        else:
-            from .utils import psnr
-            p, s = psnr(target_img, pred, 255 if pred.dtype == np.uint8 else 65535), float('nan')
+             sigma='N/A', need_degradation=False, noise_level=None, with_ssim=True, skip_failed=True) -> dict:
+    """One results_table row (scripts/tests.py:399-412).
+
+    The reference's loop lets any exception of a frame end the whole sweep (only a missing weight file is caught,
+    tests.py:48-50).  Here a frame that raises is recorded and skipped (report the failed image
+    ids instead of losing the run): the row's extra key 'Failed' lists (name, error) pairs and the statistics are
+    taken over the frames that ran; `skip_failed=False` restores the reference's behaviour (the exception
+    propagates).  Out-of-memory errors always propagate (src/utils.py:91-93 reports them to the caller)."""
+    psnr_list, ssim_list, time_list, failed = [], [], [], []
+    for input_img, target_img, name in loader:
+        try:
+            pred, ms = get_model_prediction(model, input_img, device, **patch_config, need_degradation=need_degradation,
+                                            noise_level=noise_level)
+            if with_ssim:
+                p, s = calculate_metrics(pred, target_img)
+            else:
+                from .utils import psnr
+                p, s = psnr(target_img, pred, 255 if pred.dtype == np.uint8 else 65535), float('nan')
+        except Exception as e:                                  # noqa: BLE001 (reported, not swallowed)
+            if not skip_failed or "out of memory" in str(e).lower():
+                raise
+            failed.append((name, f"{type(e).__name__}: {e}"))
+            print(f"[harness] {model_name} on {dataset}: frame {name} failed ({type(e).__name__}: {e}); skipped")
+            continue
         psnr_list.append(p)
         ssim_list.append(s)
         time_list.append(ms)
-    return aggregate(psnr_list, ssim_list, time_list, task=task, subtask=subtask, dataset=dataset, sigma=sigma,
-                     model_name=model_name, params=get_model_total_parameters(model))
+    row = aggregate(psnr_list, ssim_list, time_list, task=task, subtask=subtask, dataset=dataset, sigma=sigma,
+                    model_name=model_name, params=get_model_total_parameters(model))
+    row['Failed'] = failed
+    return row
 
 
 def aggregate(psnr_list, ssim_list, time_list, *, task, subtask, dataset, sigma, model_name, params) -> dict:
+    if not psnr_list:                      # every frame failed: an empty row, not a numpy warning
+        psnr_list = ssim_list = time_list = [float('nan')]
     return {'Task': task.capitalize(), 'Type': subtask.capitalize(), 'Dataset': dataset, 'Sigma': sigma,
             'Model': model_name, 'Model_Params': params, 'PSNR': np.mean(psnr_list), 'SSIM': np.mean(ssim_list),
             'Std_PSNR': np.std(psnr_list), 'Std_SSIM': np.std(ssim_list), 'Avg_Time_ms': np.mean(time_list),
@@ -54,7 +71,7 @@ def save_results(rows: list, out_dir: str = 'results', file_name: str = 'results
     os.makedirs(out_dir, exist_ok=True)
     path = os.path.join(out_dir, file_name)
     with open(path, 'w', newline='') as f:
-        wr = csv.DictWriter(f, fieldnames=COLUMNS)
+        wr = csv.DictWriter(f, fieldnames=COLUMNS, extrasaction='ignore')
         wr.writeheader()
         for r in rows:
             wr.writerow(r)

@@ -143,6 +143,7 @@ class Restormer(nn.Module):
         #: tiles of one image processed per forward by the device tiler (utils.tiled_forward_device)
         self.max_tiles_per_batch = 9
         self.hip_graph = True      # the tiler replays the per-batch forward from a HIP graph (utils.graphed_forward)
+        self._tap = None           # tests: a dict that receives a copy of the `refinement` output (restormer.py:274)
 
     # ------------------------------------------------------------------ weights
     def load_synthetic(self, seed=42):
@@ -449,6 +450,9 @@ class Restormer(nn.Module):
         self._c3(pk["up2_1"], dec2, cat1[:, :d1], d2, d2 * 2, H2, W2, store_mode=2)
         self._run_stage("decoder_level1", pk, cat1)
         self._run_stage("refinement", pk, cat1)          # (first block recomputes its statistics)
+        tap = self.__dict__.get("_tap")
+        if tap is not None:                              # test tap: the trunk output before the `output` conv
+            tap["refinement"] = cat1.clone()
 
         out = torch.empty(B, self.out_channels, H, W, dtype=torch.float32, device=dev)
         if self.dual_pixel_task:

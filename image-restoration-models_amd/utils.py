@@ -213,12 +213,18 @@ def _window_on(device, ps: int) -> torch.Tensor:
     return _WINDOW_CACHE[key]
 
 
-#: (model id, input shape, device, stream, weights version) -> (graph, static input, static output)
-_GRAPHS: dict = {}
+#: bound of the per-model graph cache: entries, and bytes of graph-owned memory (static buffers + workspaces)
+_GRAPH_MAX_ENTRIES, _GRAPH_MAX_BYTES = 8, 96 << 30
 
 
 def _weights_version(model: Module):
     return _hip.param_key(model)
+
+
+def _release_workspace(model: Module):
+    rel = getattr(model, "release_workspace", None)
+    if callable(rel):
+        rel()
 
 
 def graphed_forward(model: Module, x: torch.Tensor) -> torch.Tensor:
@@ -226,27 +232,46 @@ def graphed_forward(model: Module, x: torch.Tensor) -> torch.Tensor:
     the host's launch rate (hundreds of kernels of 10-60 us per image), not by the GPU.
 
     Opt-in per model (`model.hip_graph = True`, the default of the built-in model classes); off while a KernelTimer
-    is installed (per-launch events need eager launches) and with IRM_NO_GRAPH=1.  The first call for a (model, input
-    shape, stream, weights version) runs eagerly once (weight packing, workspace allocation, LDS attributes), then
-    captures the forward on torch's capture stream - every kernel of libirm_hip.so is enqueued on torch's current
-    stream and allocates nothing, so the capture holds plain kernel nodes; later calls copy the input into the
-    graph's static buffer and replay.  The returned tensor is the graph's static output: consume it (on the same
-    stream) before the next call, as the tiler does."""
+    is installed (per-launch events need eager launches) and with IRM_NO_GRAPH=1.  The first call for an (input
+    shape, stream, weights version) runs eagerly once (weight packing, LDS attributes), then captures the forward on
+    torch's capture stream - every kernel of libirm_hip.so is enqueued on torch's current stream and allocates
+    nothing, so the capture holds plain kernel nodes; later calls copy the input into the graph's static buffer and
+    replay.  The returned tensor is the graph's static output: consume it (on the same stream) before the next call,
+    as the tiler does.
+
+    Ownership: a graph's kernels hold raw pointers, so every buffer they touch must live exactly as long as the
+    graph.  The model's workspace is therefore dropped before the capture (`release_workspace()`), re-allocated
+    INSIDE it - from the graph's private memory pool - and dropped again afterwards: the pool keeps those blocks for
+    the graph alone, and no later eager call, other input shape or other graph can be handed the same memory
+    (DnCNN's eagerly allocated layer buffers were freed on a shape change while an older graph still wrote
+    to them).  The graphs live on the model object (`model._irm_graphs`), so they die with it; entries of other
+    weight versions are dropped, the rest is bounded (least recently used)."""
     if (ops.TIMER is not None or not getattr(model, "hip_graph", False) or os.environ.get("IRM_NO_GRAPH")
             or not x.is_cuda or torch.cuda.is_current_stream_capturing()):
         return model(x)
-    key = (id(model), tuple(x.shape), x.device.index, torch.cuda.current_stream().cuda_stream, _weights_version(model))
-    ent = _GRAPHS.get(key)
+    graphs = model.__dict__.get("_irm_graphs")
+    if graphs is None:
+        graphs = model.__dict__["_irm_graphs"] = {}
+    version = _weights_version(model)
+    key = (tuple(x.shape), x.device.index, torch.cuda.current_stream().cuda_stream, version)
+    ent = graphs.pop(key, None)
     if ent is None:
-        for k in [k for k in _GRAPHS if k[0] == id(model) and (k[4] != key[4] or len(_GRAPHS) > 16)]:
-            del _GRAPHS[k]                           # stale weights / bounded cache
-        model(x)                                     # eager warm-up
+        for k in [k for k in graphs if k[3] != version]:
+            del graphs[k]                            # stale weights
+        model(x)                                     # eager warm-up (packs weights, sets kernel attributes)
+        _release_workspace(model)
         static_in = x.clone()
         g = torch.cuda.CUDAGraph()
+        before = torch.cuda.memory_reserved(x.device)
         with torch.cuda.graph(g):
             static_out = model(static_in)
-        ent = _GRAPHS[key] = (g, static_in, static_out)
-    g, static_in, static_out = ent
+        _release_workspace(model)                    # the buffers stay reserved in g's private pool
+        ent = (g, static_in, static_out, max(torch.cuda.memory_reserved(x.device) - before, 0))
+        while graphs and (len(graphs) >= _GRAPH_MAX_ENTRIES
+                          or sum(e[3] for e in graphs.values()) + ent[3] > _GRAPH_MAX_BYTES):
+            del graphs[next(iter(graphs))]           # least recently used first (dict order = recency, see below)
+    graphs[key] = ent                                # (re-)insert at the end: most recently used
+    g, static_in, static_out, _ = ent
     static_in.copy_(x)
     g.replay()
     return static_out

@@ -14,7 +14,7 @@ What it does
      the max-abs differences in tests/golden/MANIFEST.json;
   3. stores the REFERENCE outputs (not the oracle's) as golden vectors.
 
-Usage: python oracle/gen_golden.py [--only restormer|tiler|convnets|ops|deblurgan|fpn_inception|fullsize|fullsize_c3|fullsize_c5|demo|mair]
+Usage: python oracle/gen_golden.py [--only restormer|tiler|convnets|ops|deblurgan|fpn_inception|fullsize|fullsize_frame|fullsize_c3|fullsize_c5|demo|mair]
 """
 from __future__ import annotations
 
@@ -545,6 +545,45 @@ def gen_fullsize(ref, manifest):
                                       "config": "deblur_withbias", "weights_seed": 42}
 
 
+def gen_fullsize_frame(ref, manifest):
+    """BASELINE.json configs[3] end to end: the reference's OWN tiled-patch loop (src/utils.py:353-454, through
+    get_model_prediction) with the reference Restormer (motion-deblur configuration, synthetic weights seed 42) on the
+    benchmark's first synthetic 1280x720 frame, PATCH_CONFIG 512 / 96 (6 tiles).  Fixture: the whole uint8 frame, its
+    sha256 and its PSNR against the synthetic target.  The same run also taps the 96-channel output of `refinement`
+    (restormer.py:274, the tensor BEFORE the 0.02-gain `output` conv of the synthetic weights) on tile 0: every 16th
+    pixel + one row + moments - full-size parity on an un-attenuated tensor."""
+    from irm_amd.restormer import restormer as prod
+    U = ref.utils
+    kw = RESTORMER_CFGS["deblur_withbias"]
+    net = ref.rmod.Restormer(**kw).eval()
+    sd = synth.synth_state_dict(shapes_of(net), seed=42, rules=prod.SYNTH_RULES)
+    net.load_state_dict(sd, strict=True)
+    inp, tgt = synth.synth_image_pair(0, 720, 1280, 3, seed_base=1000, blur=15)
+    cfg = U.get_patch_config("deblurring", "motion", "Restormer")
+    taps = []
+    hook = net.refinement.register_forward_hook(lambda m, i, o: taps.append(o[0].numpy().copy()) if not taps else None)
+    import time
+    t0 = time.time()
+    pred, _ = U.get_model_prediction(net, inp, torch.device("cpu"), **cfg)
+    hook.remove()
+    dt = time.time() - t0
+    assert pred.shape == inp.shape and pred.dtype == np.uint8 and len(taps) == 1 and taps[0].shape == (96, 512, 512)
+    psnr = tiler_ref.psnr(tgt, pred)
+    psnr_in = tiler_ref.psnr(tgt, inp)
+    r = taps[0]
+    print(f"fullsize frame: reference run_model_inference on 1280x720 (cfg {cfg}) took {dt:.0f} s; PSNR {psnr:.4f} dB "
+          f"(input {psnr_in:.4f}); refinement tap range [{r.min():.3f},{r.max():.3f}] rms {np.sqrt((r.astype(np.float64) ** 2).mean()):.3f}")
+    np.savez_compressed(os.path.join(GOLD, "restormer_fullsize_frame.npz"), pred_u8=pred,
+                        sha256=np.frombuffer(bytes.fromhex(sha(pred)), dtype=np.uint8), psnr=np.float64(psnr),
+                        psnr_input=np.float64(psnr_in),
+                        refine_sub16=r[:, ::16, ::16], refine_row100=r[:, 100, :], refine_mean=r.mean(axis=(1, 2)),
+                        refine_sqmean=(r.astype(np.float64) ** 2).mean(axis=(1, 2)))
+    manifest["restormer_fullsize_frame"] = {
+        "input": "synth_image_pair(0,720,1280,3,seed_base=1000,blur=15)", "config": "deblur_withbias", "weights_seed": 42,
+        "patch_config": cfg, "reference_seconds": round(dt), "psnr_db": psnr, "sha256_u8": sha(pred),
+        "refinement_tap": "net.refinement output of the first tile (origin 0,0), forward hook"}
+
+
 def gen_fullsize_c3(ref, manifest):
     """BASELINE.json configs[2] (Restormer colour blind-denoise, BiasFree LayerNorm) at its full tile size: the
     reference model on tile 0 (256x256, PATCH_CONFIG denoising) of a 512x512 synthetic frame with sigma = 25 noise
@@ -631,7 +670,7 @@ def main():
     manifest = json.load(open(mpath)) if os.path.exists(mpath) else {}
     ref = import_reference()
     steps = {"ops": gen_ops, "restormer": gen_restormer, "convnets": gen_convnets, "tiler": gen_tiler,
-             "deblurgan": gen_deblurgan, "fpn_inception": gen_fpn_inception, "fullsize": gen_fullsize, "fullsize_c3": gen_fullsize_c3, "demo": gen_demo, "mair": gen_mair,
+             "deblurgan": gen_deblurgan, "fpn_inception": gen_fpn_inception, "fullsize": gen_fullsize, "fullsize_frame": gen_fullsize_frame, "fullsize_c3": gen_fullsize_c3, "demo": gen_demo, "mair": gen_mair,
              "fullsize_c5": gen_fullsize_c5}      # mair last: it re-stubs the `mair` package for the reference's arch file
     for k, fn in steps.items():
         if args.only in (None, k):

@@ -431,3 +431,18 @@ def test_presplit_host_side_packing_and_plans():
                 assert ct in (4, 6, 8) and 1 <= mg <= chunks and (mg - 1) * -(-chunks // mg) < chunks
                 assert shape == (43 if K == 192 else 81)
     assert _hip.plan_presplit(64, 6144, 192) == (4, 1, 43) and _hip.plan_presplit(128, 1536, 384) == (8, 4, 81)
+
+
+def test_fullsize_frame_fixture_is_self_consistent():
+    """tests/golden/restormer_fullsize_frame.npz (the reference's run_model_inference on bench frame 0): the stored
+    sha256 and PSNR are those of the stored uint8 frame against the regenerated synthetic target, and the input it
+    was produced from is the frame bench.py feeds to rank 0 (PSNR of the raw input recorded beside it)."""
+    import hashlib
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "restormer_fullsize_frame.npz"))
+    pred = g["pred_u8"]
+    assert pred.shape == (720, 1280, 3) and pred.dtype == np.uint8
+    assert hashlib.sha256(np.ascontiguousarray(pred).tobytes()).digest() == g["sha256"].tobytes()
+    inp, tgt = synth.synth_image_pair(0, 720, 1280, 3, seed_base=1000, blur=15)
+    assert abs(tiler_ref.psnr(tgt, pred) - float(g["psnr"])) < 1e-9
+    assert abs(tiler_ref.psnr(tgt, inp) - float(g["psnr_input"])) < 1e-9
+    assert g["refine_sub16"].shape == (96, 32, 32) and g["refine_row100"].shape == (96, 512)

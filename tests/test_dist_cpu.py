@@ -63,6 +63,52 @@ def test_two_rank_shard_and_gather():
         assert abs(p - tiler_ref.psnr(tgt, inp)) < 1e-9
 
 
+def _worker_ragged(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import irm_amd  # noqa: F401
+    from irm_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rank 0: three rows of width 4 (id, psnr, ssim, ms), no failed_ids argument at all; rank 1: every frame failed
+    if rank == 0:
+        res = parallel.gather_results(0.5, [(i, 30.0 + i, 0.9, 12.5) for i in range(3)], torch.device("cpu"))
+    else:
+        res = parallel.gather_results(0.25, [], torch.device("cpu"), failed_ids=[7, 5])
+    q.put((rank, res[0], res[1].tolist(), list(res[2]) if len(res) > 2 else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_with_an_empty_rank_wider_rows_and_mixed_failed_ids():
+    """a rank without rows must not fix the padded width at 2, and ranks that pass / do not pass
+    failed_ids must still run the same collectives."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = dict((r[0], r[1:]) for r in (q.get(), q.get()))
+    for rank in (0, 1):
+        tmax, table, failed = got[rank]
+        assert tmax == 0.5 and np.array(table).shape == (3, 4) and table[2] == [2.0, 32.0, 0.9, 12.5]
+        assert failed == (None if rank == 0 else [5, 7])
+
+
+def test_gather_single_process():
+    sys.path.insert(0, ROOT)
+    import irm_amd  # noqa: F401
+    from irm_amd import parallel
+    t, tab, failed = parallel.gather_results(1.5, [(0, 31.0), (1, 29.0)], torch.device("cpu"), failed_ids=[3])
+    assert t == 1.5 and tab.tolist() == [[0.0, 31.0], [1.0, 29.0]] and failed == [3]
+    t, tab = parallel.gather_results(1.5, [], torch.device("cpu"))
+    assert tab.shape[0] == 0
+
+
 def test_shard_is_a_partition():
     sys.path.insert(0, ROOT)
     import irm_amd  # noqa: F401

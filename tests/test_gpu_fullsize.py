@@ -46,6 +46,54 @@ def test_fullsize_tile_vs_reference_golden(dev, model, frame, golden):
     assert err <= 1e-3 and m_err <= 1e-5 and s_err <= 1e-5
 
 
+def test_fullsize_whole_frame_vs_reference_run_model_inference(dev, model, frame, golden):
+    """BASELINE configs[3] end to end against the REFERENCE's own tiled-patch loop (src/utils.py:353-454 through
+    get_model_prediction, reference Restormer, CPU; gen_golden.py --only fullsize_frame, 134 s): the 1280x720 uint8
+    frame of the GPU path differs from the reference's by at most 1 in fewer than 0.1 % of its bytes, and the PSNR
+    against the synthetic target agrees within north_star's 0.01 dB."""
+    g = golden("restormer_fullsize_frame")
+    inp, tgt = frame
+    out, sse = utils.tiled_forward_device(model, torch.from_numpy(inp).to(dev), PS, OV, pad8=True,
+                                          target_dev=torch.from_numpy(tgt).to(dev), max_batch=8)
+    out = out.cpu().numpy()
+    ref = g["pred_u8"]
+    assert out.shape == ref.shape == (H, W, 3) and out.dtype == np.uint8
+    diff = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    psnr_gpu = 10 * np.log10(255.0 ** 2 / (float(sse.item()) / out.size))
+    assert abs(psnr_gpu - tiler_ref.psnr(tgt, out)) < 1e-9                      # device SSE == host PSNR of the same bytes
+    print(f"whole frame vs the reference's run_model_inference: {int((diff > 0).sum())} of {diff.size} bytes differ "
+          f"(max {int(diff.max())}); PSNR gpu {psnr_gpu:.5f} dB, reference {float(g['psnr']):.5f} dB")
+    assert int(diff.max()) <= 1 and float((diff > 0).mean()) < 1e-3
+    assert abs(psnr_gpu - float(g["psnr"])) < 0.01
+    # the product's reference-shaped host call gives the same bytes as the device pipeline
+    pred, _ = utils.get_model_prediction(model, inp, dev, **utils.get_patch_config("deblurring", "motion", "Restormer"))
+    assert np.array_equal(pred, out)
+
+
+def test_fullsize_unattenuated_trunk_vs_reference_golden(dev, model, frame, golden):
+    """The whole-model goldens are taken behind the 0.02 gain of the synthetic `output` conv (restormer.py SYNTH_RULES),
+    which attenuates every trunk error ~50x.  Here the 96-channel output of `refinement`
+    (reference restormer.py:274, values up to +-19, rms 3.3) of the full 512x512 tile 0 is compared directly with the
+    reference's tensor (forward hook in gen_golden.py --only fullsize_frame): north_star's 1e-3 max-abs on an
+    un-attenuated tensor, relative to its rms as well."""
+    g = golden("restormer_fullsize_frame")
+    tap = {}
+    model._tap = tap
+    try:
+        model(_tile0(frame, dev))
+    finally:
+        model._tap = None
+    r = tap["refinement"][0].cpu().numpy()
+    assert r.shape == (96, PS, PS)
+    err = max(np.abs(r[:, ::16, ::16] - g["refine_sub16"]).max(), np.abs(r[:, 100, :] - g["refine_row100"]).max())
+    rms = float(np.sqrt((g["refine_sub16"].astype(np.float64) ** 2).mean()))
+    m_err = np.abs(r.mean(axis=(1, 2)) - g["refine_mean"]).max()
+    s_err = np.abs((r.astype(np.float64) ** 2).mean(axis=(1, 2)) - g["refine_sqmean"]).max()
+    print(f"refinement output (96 x 512 x 512, rms {rms:.2f}, max |.| {np.abs(g['refine_sub16']).max():.1f}) vs reference: "
+          f"max-abs {err:.3e} ({err / rms:.2e} of rms), channel mean {m_err:.2e}, mean square {s_err:.2e}")
+    assert err <= 1e-3 and m_err <= 1e-4 and s_err <= 1e-3
+
+
 def _check_sub(y, g, sub, row):
     err = max(np.abs(y[:, ::sub, ::sub] - g[f"sub{sub}"]).max(), np.abs(y[:, row, :] - g[f"row{row}"]).max())
     m_err = np.abs(y.mean(axis=(1, 2)) - g["mean"]).max()
@@ -130,11 +178,11 @@ def test_fullsize_two_streams_and_graph_replay(dev, model, frame, monkeypatch):
     base = base.clone()
     monkeypatch.delenv("IRM_NO_GRAPH")
     assert model.hip_graph
-    utils._GRAPHS.clear()
+    model.__dict__.pop("_irm_graphs", None)
     for _ in range(2):                      # capture, then replay
         g, _ = utils.tiled_forward_device(model, img, PS, OV, pad8=True, max_batch=8)
         assert torch.equal(g, base)
-    assert len(utils._GRAPHS) == 1
+    assert len(model._irm_graphs) == 1
     model.num_streams = 2
     try:
         runs = [utils.tiled_forward_device(model, img, PS, OV, pad8=True, max_batch=8)[0].clone() for _ in range(3)]

@@ -185,3 +185,25 @@ def test_fused_trained_like_statistics(dev, act_scale, ln):
     e16, e32 = float((yq.cpu().double() - refq).abs().max()), float((q32.cpu().double() - refq).abs().max())
     print(f"qkv  act x{act_scale:g} ln{ln}: |ref|max {scale:.3e}  fused {e16:.3e}  fp32 chain {e32:.3e}")
     assert e16 <= 1e-3 * max(1.0, scale) and e16 <= 2.0 * e32 + 4e-7 * scale
+
+
+def test_gate_out_of_range_saturates_instead_of_nan(dev):
+    """the gated activations are split to fp16 behind a fixed 2^-4 scale.  |gelu(h1) h2| beyond ~1e6 used to
+    become fp16 infinities and a NaN output tile; the scaled value is now saturated at +-65000 before the split
+    (irm_sat_h), in the fused branch kernel and in the streaming emulated GEMM alike: the result is finite (and, being
+    out of the emulation's documented range, not accurate)."""
+    C, hid, H, W = 96, 255, 16, 32
+    x = rnd("satx", (1, C, H, W), -1.5, 2.0).to(dev)
+    pin_w = rnd("satpi", (2 * hid, C), -600.0, 600.0)
+    dw_w, pout_w = rnd("satdw", (2 * hid, 9), -0.4, 0.4), rnd("satpo", (C, hid), -0.1, 0.1)
+    lnw, lnb = rnd("satlw", (C,), 0.5, 1.5), rnd("satlb", (C,), -0.2, 0.2)
+    ref = gdfn_ref(x.cpu(), lnw, lnb, 1, pin_w, None, dw_w, None, pout_w, None)
+    gate_max = float((ref - x.cpu().double()).abs().max())
+    y = torch.empty_like(x)
+    ops.gdfn_fused(_hip.pack_gdfn_fused(pin_w.to(dev), None, dw_w, None, pout_w, lnw, lnb), x, y, C, hid, ln_mode=1)
+    assert gate_max > 1e6 and bool(torch.isfinite(y).all())
+    # streaming emulated GEMM without the LayerNorm prologue (2^-4 split of the raw input)
+    g = (rnd("satg", (1, hid, H, W), -1.0, 1.0) * 3e7).to(dev)
+    out = torch.empty_like(x)
+    ops.gemm1x1(_hip.pack_gemm_weight_split(pout_w.to(dev)), g, out, C, hid, res=x, split=True)
+    assert bool(torch.isfinite(out).all())

@@ -45,6 +45,25 @@ def test_harness_evaluate_rows_vs_oracle_tiler(dev, tmp_path):
     assert list(rd[0].keys()) == harness.COLUMNS and abs(float(rd[0]["PSNR"]) - row["PSNR"]) < 1e-9
 
 
+def test_harness_reports_a_failed_frame_and_keeps_the_rest(dev, tmp_path):
+    """a frame that raises (here: a 2-D float array the tiler cannot index) is listed in the row's
+    'Failed' entry with its name, the statistics cover the frames that ran, the CSV keeps the reference's columns;
+    skip_failed=False propagates like the reference's loop (scripts/tests.py:389-398 catches nothing)."""
+    model = dncnn.DnCNN(1, 1, 64, 17, "R").load_synthetic(42).eval().to(dev)
+    cfg = utils.get_patch_config("denoising", "gaussian", "DnCNN")
+    good = list(harness.synthetic_loader(2, h=64, w=96, c=1, seed_base=5, blur=3))
+    bad = (np.zeros((64, 96), np.float32), good[0][1], "broken.png")
+    kw = dict(task="denoising", subtask="gaussian", dataset="synthetic", model_name="DnCNN", with_ssim=False)
+    row = harness.evaluate(model, iter([good[0], bad, good[1]]), dev, cfg, **kw)
+    assert [n for n, _ in row["Failed"]] == ["broken.png"] and np.isfinite(row["PSNR"])
+    ref = harness.evaluate(model, iter(good), dev, cfg, **kw)
+    assert ref["Failed"] == [] and abs(ref["PSNR"] - row["PSNR"]) < 1e-9 and abs(ref["Std_PSNR"] - row["Std_PSNR"]) < 1e-9
+    with open(harness.save_results([row], out_dir=str(tmp_path))) as f:
+        assert list(csv.DictReader(f).fieldnames) == harness.COLUMNS
+    with pytest.raises(Exception):
+        harness.evaluate(model, iter([bad]), dev, cfg, skip_failed=False, **kw)
+
+
 def test_gather_carries_failed_image_ids(dev):
     t, table, failed = parallel.gather_results(0.5, [(0, 30.0), (2, 31.0)], dev, failed_ids=[1])
     assert t == 0.5 and table.shape == (2, 2) and failed == [1]

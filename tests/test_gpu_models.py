@@ -306,9 +306,9 @@ def test_graph_replay_equals_eager(dev, family, monkeypatch):
     monkeypatch.setenv("IRM_NO_GRAPH", "1")
     eager = [run(i) for i in range(3)]
     monkeypatch.delenv("IRM_NO_GRAPH")
-    utils._GRAPHS.clear()
+    model.__dict__.pop("_irm_graphs", None)
     graphed = [run(i) for i in range(3)] + [run(0)]
-    assert len(utils._GRAPHS) >= 1
+    assert len(model._irm_graphs) >= 1
     for a, b in zip(eager + [eager[0]], graphed):
         assert torch.equal(a, b)
     # new weights -> the old graph must not be replayed
@@ -317,3 +317,35 @@ def test_graph_replay_equals_eager(dev, family, monkeypatch):
     e2 = run(1)
     monkeypatch.delenv("IRM_NO_GRAPH")
     assert torch.equal(run(1), e2) and not torch.equal(e2, eager[1])
+
+
+def test_graphs_own_their_workspace_across_alternating_shapes(dev, monkeypatch):
+    """DnCNN keeps layer buffers per (B, H, W); a 256^2 image (1 tile), then a 512^2 image (9 tiles at
+    patch 256 / overlap 32: batches of 8 + 1), then the 256^2 image again replay the B = 1 graph after the buffers it
+    was captured with were replaced.  Every frame must equal the eager bytes; so must a frame after a MIDDLE layer's
+    Parameter object was swapped (the weight fingerprint has to see it)."""
+    from irm_amd import dncnn
+    model = dncnn.DnCNN(1, 1, 64, 17, "R").load_synthetic(42).eval().to(dev)
+    cfg = utils.get_patch_config("denoising", "gaussian", "DnCNN")
+    imgs = [torch.from_numpy(synth.synth_image_pair(i, s, s, 1, seed_base=60, blur=3)[0]).to(dev)
+            for i, s in enumerate((256, 512, 256, 512, 256))]
+
+    def run(i):
+        return utils.tiled_forward_device(model, imgs[i], cfg["patch_size"], cfg["patch_overlap"], pad8=False,
+                                          noise_sigma=25, max_batch=8)[0].clone()
+    monkeypatch.setenv("IRM_NO_GRAPH", "1")
+    eager = [run(i) for i in range(len(imgs))]
+    monkeypatch.delenv("IRM_NO_GRAPH")
+    model.__dict__.pop("_irm_graphs", None)
+    graphed = [run(i) for i in range(len(imgs))]
+    assert len(model._irm_graphs) == 2                   # B = 1 (also the ninth tile of the 512^2 image) and B = 8
+    for i, (a, b) in enumerate(zip(eager, graphed)):
+        assert torch.equal(a, b), f"image {i}: graph replay differs from the eager bytes"
+    conv = [m for m in model.model if isinstance(m, torch.nn.Conv2d)][8]
+    conv.weight = torch.nn.Parameter(conv.weight.detach() * 0.5)
+    monkeypatch.setenv("IRM_NO_GRAPH", "1")
+    e2 = run(0)
+    monkeypatch.delenv("IRM_NO_GRAPH")
+    g2 = run(0)
+    assert torch.equal(g2, e2) and not torch.equal(e2, eager[0])
+    del model                                            # the graphs and their pools die with the model object

@@ -34,6 +34,8 @@ for k in sorted(set(fetch) | set(write)):
     r = out[k]
     if r["hbm_read_bytes_per_launch"] is not None and r["hbm_write_bytes_per_launch"] is not None:
         r["hbm_bytes_per_launch"] = r["hbm_read_bytes_per_launch"] + r["hbm_write_bytes_per_launch"]
+# frames the profiled command processed = launches of the per-frame blend kernel (bench.py: step_model.hbm_util)
+out["_frames"] = sum(v["launches"] for k, v in out.items() if k.startswith("blend_kernel"))
 import subprocess
 try:
     out["_git_sha"] = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True,
