@@ -261,7 +261,7 @@ def main():
             os.close(saved)
 
     model = restormer.Restormer(LayerNorm_type="WithBias").load_synthetic(42).eval().to(dev)
-    model.num_streams = args.streams
+    model.num_streams = args.streams                        # (> 1: experimental, needs IRM_EXPERIMENTAL_STREAMS=1)
     cfg = PATCH_CONFIG["Restormer"][1]                      # deblurring: 512 / 96
     frames, targets, host_frames = [], [], []
     for i in range(N_FRAMES):

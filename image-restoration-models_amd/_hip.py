@@ -396,7 +396,7 @@ def _split_h(t32: torch.Tensor):
     return hi, lo
 
 
-def pack_gdfn_fused(pin_w, pin_b, dw_w, dw_b, pout_w, lnw, lnb):
+def pack_gdfn_fused(pin_w, pin_b, dw_w, dw_b, pout_w, lnw, lnb, gate_prescale: bool = True):
     """Operands of irm_gdfn_fused_f16x3_f32 (include/irm_hip.h) from the reference's parameters
     (FeedForward.project_in / dwconv / project_out and norm2, restormer.py:76-93, 141):
     returns (rec, w2, inv_s1, inv_s2).  The LayerNorm weight is folded into project_in (W diag(w)) and the
@@ -431,6 +431,10 @@ def pack_gdfn_fused(pin_w, pin_b, dw_w, dw_b, pout_w, lnw, lnb):
     dwf[:, :hid, :9] = dw_w.detach().reshape(2 * hid, 9).float().cpu().view(2, hid, 9)
     if dw_b is not None:
         dwf[:, :hid, 9] = dw_b.detach().float().cpu().view(2, hid)
+    # the gate multiplies gelu(dw(h1)) by dw(h2) / 16 (the fp16 split range of the gated activations): a power of
+    # two on the taps and the bias of the second half scales every partial sum of its stencil exactly
+    if gate_prescale:                       # (False: the operand layout of builds before round 3, tools/ab_fused.py)
+        dwf[1] *= 0.0625
     coef = dwf.view(2, S, 16, 10).permute(1, 3, 0, 2).contiguous().view(S, 320)     # [S][t][hct*16+m]
     b1f = torch.zeros(2, 16 * S, dtype=torch.float32)
     b1f[:, :hid] = b1.float().view(2, hid)

@@ -50,6 +50,7 @@ struct ConvArgs {
 
 template <int CT>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
+    IRM_KERNEL_ENTRY();
     __shared__ float xs[2][CV_CK * CV_PLANE];
     // packed weights of one stage (9 taps x CT tiles x 2 k-steps x 64 lanes), double buffered like xs: read
     // from global once per stage with coalesced loads instead of one dependent load per tap inside the MFMA loop
@@ -253,6 +254,7 @@ __device__ __forceinline__ void cv_wait_vmcnt() {
 
 template <int CT, int NS>
 __global__ __launch_bounds__(256, 2) void conv3x3_ring_kernel(ConvArgs a) {
+    IRM_KERNEL_ENTRY();
     constexpr int XU = 8;                          // 1 KiB units of the input image per stage (400 chunks + pad:
                                                    // every wave issues the same number of DMA instructions)
     constexpr int WCH = 9 * CT * 16;               // 16-byte chunks of weights per stage

@@ -52,6 +52,7 @@ __device__ __forceinline__ void cf_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(
 
 template <int CT>
 __global__ __launch_bounds__(512, 2) void conv3x3_f16x3_kernel(ConvF16Args a) {
+    IRM_KERNEL_ENTRY();
     constexpr int WGB = 3 * CT * 2048;             // bytes of the weights of one tap group (3 taps)
     constexpr int NW = (WGB / 16 + 511) / 512;     // weight DMA instructions per lane and tap group
     extern __shared__ __attribute__((aligned(16))) float smem[];

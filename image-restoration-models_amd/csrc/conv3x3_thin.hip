@@ -47,6 +47,7 @@ __device__ __forceinline__ float thin_epilogue(float v, float bias, float r, con
 // partial sums meet in LDS in wave order (bitwise reproducible), wave 0 applies the epilogue and stores.
 template <int CO, int RS>
 __global__ __launch_bounds__(256) void conv3x3_thin_out_kernel(ThinArgs a) {
+    IRM_KERNEL_ENTRY();
     __shared__ float part[3][CO * RS * 4][64];
     const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long item = (long)blockIdx.x * 64 + lane;
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void conv3x3_thin_out_kernel(ThinArgs a) {
 // workgroup's range are produced one after the other (their 9 CI weights are wave-uniform) and stored at once.
 template <int CI, int RS>
 __global__ __launch_bounds__(256) void conv3x3_thin_in_kernel(ThinArgs a, int co_per_group) {
+    IRM_KERNEL_ENTRY();
     const long item = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)a.strips * a.cgs;
     if (item >= total) return;

@@ -145,6 +145,7 @@ typedef _Float16 dg_h4 __attribute__((ext_vector_type(4)));
 template <int CT, bool GATE, int NS, int PT, bool F16 = false, int TW = 32>
 __global__ __launch_bounds__((PT == 4 ? 256 : 512) * (TW / 32), TW == 64 ? 1 : (PT == 4 ? (CT <= 3 ? 3 : 2) : 2))
 void dwgemm_kernel(DwGemmArgs a) {
+    IRM_KERNEL_ENTRY();
     constexpr int CH = TW / 4 + 2;                 // 16-byte chunks per halo row
     constexpr int RF = CH * 4, PL = 10 * RF;       // floats per halo row / plane
     constexpr int NWX = TW / 16;                   // wave columns

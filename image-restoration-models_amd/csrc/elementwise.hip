@@ -15,6 +15,7 @@
 template <bool VEC, int PQ>
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, long x_bs,
                                                        float* __restrict__ stats, int C, int N, float eps) {
+    IRM_KERNEL_ENTRY();
     constexpr int G = 256 / PQ;
     __shared__ float4 pm[G][PQ], pq[G][PQ];
     const int b = blockIdx.y;
@@ -135,6 +136,7 @@ __device__ __forceinline__ float4 dw_apply(const float (&k)[9], const float (&r0
 
 template <bool GATE, int RS, bool VEC>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs a) {
+    IRM_KERNEL_ENTRY();
     const int cgs = (a.W + 3) >> 2;
     const int strips = (a.H + RS - 1) / RS;
     const long total = (long)a.C * strips * cgs;

@@ -23,6 +23,7 @@ __device__ __forceinline__ float block_sum256(float v, float* sh) {
 
 __global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ st,
                                                          int C, int N, float eps) {
+    IRM_KERNEL_ENTRY();
     __shared__ float sh[4];
     const int c = blockIdx.x, b = blockIdx.y;
     const float* p = x + (long)b * x_bs + (long)c * N;
@@ -64,6 +65,7 @@ __device__ __forceinline__ WF wf_merge(WF a, WF b) {
 
 __global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restrict__ x, long x_bs, float* __restrict__ ws,
                                                            int C, int N, int nsplit) {
+    IRM_KERNEL_ENTRY();
     __shared__ WF sh[4];
     const int sp = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
     const float4* p = reinterpret_cast<const float4*>(x + (long)b * x_bs + (long)c * N);
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restri
 
 __global__ __launch_bounds__(64) void chan_finish_kernel(const float* __restrict__ ws, float* __restrict__ st, int planes,
                                                          int nsplit, float eps) {
+    IRM_KERNEL_ENTRY();
     const int pl = blockIdx.x * 64 + threadIdx.x;
     if (pl >= planes) return;
     const float* w = ws + (long)pl * nsplit * 3;
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(256) void chan_norm_act_kernel(const float* __restr
                                                             const float* __restrict__ bi, const float* __restrict__ res,
                                                             long r_bs, float* __restrict__ y, long y_bs, int C, int N,
                                                             int act) {
+    IRM_KERNEL_ENTRY();
     const int c = blockIdx.y, b = blockIdx.z;
     const float mean = st[((long)b * C + c) * 2], rstd = st[((long)b * C + c) * 2 + 1];
     const float g = w ? w[c] : 1.0f, be = bi ? bi[c] : 0.0f;
@@ -179,6 +183,7 @@ extern "C" int irm_chan_norm_act_f32(const float* x, long x_bs, const float* sta
 __global__ __launch_bounds__(256) void conv3x3_s2_kernel(const float* __restrict__ x, long x_bs,
                                                          const float* __restrict__ w, float* __restrict__ y, long y_bs,
                                                          int Ci, int Co, int H, int W, int Ho, int Wo) {
+    IRM_KERNEL_ENTRY();
     const int b = blockIdx.z, cg = blockIdx.y;
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= Ho * Wo) return;
@@ -224,6 +229,7 @@ extern "C" int irm_conv3x3_s2_f32(const float* x, long x_bs, const float* w, flo
 __global__ __launch_bounds__(256) void dwconv3x3_s2_kernel(const float* __restrict__ x, long x_bs,
                                                            const float* __restrict__ w, float* __restrict__ y, long y_bs,
                                                            int H, int W, int Ho, int Wo) {
+    IRM_KERNEL_ENTRY();
     const int c = blockIdx.y, b = blockIdx.z;
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= Ho * Wo) return;
@@ -260,6 +266,7 @@ extern "C" int irm_dwconv3x3_s2_f32(const float* x, long x_bs, const float* w, f
 __global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restrict__ src, long s_bs,
                                                            const float* __restrict__ add, long a_bs,
                                                            float* __restrict__ out, long o_bs, int Hs, int Ws, int s) {
+    IRM_KERNEL_ENTRY();
     const int c = blockIdx.y, b = blockIdx.z;
     const int Ho = Hs * s, Wo = Ws * s;
     const float* sp = src + (long)b * s_bs + (long)c * Hs * Ws;

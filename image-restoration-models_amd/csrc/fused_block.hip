@@ -15,7 +15,8 @@
 // The depth-wise stencil then reads, per lane, pixel r of two vertically adjacent output rows and 4 + 4 channels
 // (packed-fp32 FMAs over channel pairs), gates them, splits the result (x 2^-4) into fp16 hi/lo: exactly the
 // k-slots lane (r, g) owns in the 16x16x32 MFMA of project_out, accumulated over all stages in registers.  The
-// halo pixels outside the image are zeroed after the first GEMM (the reference zero-pads h, not x).  The 1x1
+// halo pixels outside the image read as zero in the stencil (the reference zero-pads h, not x): their image slots are
+// zeroed once per item and never written.  The 1x1
 // conv of stage s+1 and the stencil of stage s sit in one barrier interval (double-buffered LDS image), so the
 // matrix and vector pipes overlap.
 #include "irm_common.h"
@@ -26,6 +27,7 @@
 
 typedef _Float16 fb_h8 __attribute__((ext_vector_type(8)));
 typedef float fb_v2 __attribute__((ext_vector_type(2)));
+typedef unsigned fb_u4 __attribute__((ext_vector_type(4)));
 
 #define FB_INTERLEAVE 3      // plain VALU instructions scheduled behind each MFMA of a GEMM unit
 #define FB_TH 8
@@ -68,16 +70,37 @@ __device__ __forceinline__ fb_v2 fb_gelu2(fb_v2 x) {
     return sg * h + h;
 }
 
+// gelu(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2), erfc by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): with
+// u = |x| sqrt(log2(e) / 2) the exponential is exp2(-u u), the rational argument 1 + p z = 1 + (p / sqrt(log2 e)) u, and
+// the factor 0.5 |x| = u * (0.5 / c_u) is folded into the polynomial's coefficients: 14 instructions (two of them
+// transcendental) instead of 18 for the sign-select form 0.5 x (1 + copysign(1 - e, x)); no cancellation beyond a factor
+// of two anywhere (x > 0: x - [<= x / 2]).
 __device__ __forceinline__ float fb_gelu1(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(z, 0.3275911f, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = p * t * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);   // 1 - erf(|z|)
-    const float h = x * 0.5f;
-    return fmaf(copysignf(1.0f - e, x), h, h);
+    constexpr double CU = 0.84932180028801904272;            // sqrt(log2(e) / 2)
+    constexpr double F = 0.5 / CU;
+    constexpr float k = (float)(0.3275911 / 1.2011224087864498);
+    constexpr float a1 = (float)(0.254829592 * F), a2 = (float)(-0.284496736 * F), a3 = (float)(1.421413741 * F),
+                    a4 = (float)(-1.453152027 * F), a5 = (float)(1.061405429 * F);
+    const float u = fabsf(x) * (float)CU;
+    const float t = __builtin_amdgcn_rcpf(fmaf(u, k, 1.0f));
+    float p = fmaf(t, a5, a4);
+    p = fmaf(p, t, a3);
+    p = fmaf(p, t, a2);
+    p = fmaf(p, t, a1);
+    const float w = (p * t) * __builtin_amdgcn_exp2f(-u * u);     // 0.5 / c_u * erfc(|x| / sqrt 2)
+    return fmaf(-u, w, __builtin_amdgcn_fmed3f(x, 0.0f, 3.0e38f));      // (med3: max(x, 0) without fmaxf's canonicalising v_max)
+}
+
+// fp16 hi/lo split of two fp32 values into packed pairs: hi = rn16(x), lo = rn16(x - hi) - the difference is exact in
+// fp32, so v_fma_mix{lo,hi}_f16 (f16 source widened, one rounding of the result) gives exactly the two-step value in
+// one instruction per element instead of cvt + sub + cvt (hipcc does not form it from the source expression).
+__device__ __forceinline__ void fb_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    unsigned h, l;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
+    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
+    hi = h;
+    lo = l;
 }
 
 // LDS accesses as (per-lane byte offset in a VGPR) + (compile-time immediate < 64 KiB): the offsets are made opaque
@@ -144,6 +167,7 @@ __device__ __forceinline__ void fb_dma(const float* src, float* dst, int wave, i
 // so its HBM latency and the epilogue stores overlap compute, and nothing is paid per tile for workgroup launch.
 template <int KS, int CT, bool GATE>
 __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
+    IRM_KERNEL_ENTRY();
     constexpr int W1F = KS * 1024;                 // floats of project_in weights per record (2 tiles x KS x hi/lo x 1 KiB)
     constexpr int RECF = W1F + 512;                // + depth-wise taps [10][32], bias [32], pad
     constexpr int RECP = KS * 4 + 2;               // 1 KiB pieces per record
@@ -151,6 +175,9 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
     // LDS map (bytes): [2 record slots][project_out super-stage][2 images of 340 pixels x 160 B]
     constexpr int SLOT_B = RECF * 4, W2_OFF = 2 * SLOT_B, PL_OFF = W2_OFF + W2F * 4, PL_B = FB_PLF * 4;
     constexpr int CF_OFF = W1F * 4;                // taps within a slot
+    constexpr int RT = 264;                        // floats per channel row of the residual transpose (inside the image area)
+    constexpr int PARK_OFF = PL_OFF + 2 * PL_B;    // GATE: one accumulator tile per thread (8 KiB)
+    static_assert(!GATE || 32 * KS * RT * 4 <= 2 * PL_B, "residual transpose must fit the image area");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     fb_lc* lds = (fb_lc*)smem;
     float* slots = smem;
@@ -183,14 +210,12 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
         // lane geometry inside a tile (item independent)
         int hr[3], hc[3];
         bool pv[3];
-        unsigned vq[3];                                // byte offset of (pixel, channel quad g) in LDS image 0
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int p = 16 * (wave + 8 * j) + r;
             pv[j] = p < FB_NP;
             hr[j] = p / FB_HC;
             hc[j] = p - hr[j] * FB_HC;
-            vq[j] = fb_opaque((unsigned)(PL_OFF + ((pv[j] ? p : FB_NP + r) * FB_PS + 4 * g) * 4));
         }
         int klim[KS];                                  // channel 32 ks + 8 g + e exists <=> e < klim[ks] (compared where used:
 #pragma unroll                                     // 24 lane masks held in scalar registers spill)
@@ -231,7 +256,6 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
         if (round == 0) load_x(item);
         const int b = item / a.tiles, tile = item - b * a.tiles;
         const int ty0 = (tile / a.tiles_x) * FB_TH, tx0 = (tile % a.tiles_x) * FB_TW;
-        const float* X = a.X + (long)b * a.x_bs;
         float* Y = a.Y + (long)b * a.y_bs;
         const int nitem = item_of(round + 1);
 
@@ -241,17 +265,49 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
         fb_dma<RECP>(a.rec + RECF, slots, wave, lane);                  // record 1 (iteration 0)   -> slot 0
         if constexpr (GATE) fb_dma<W2P>(a.w2, w2a, wave, lane);
 
+        // Where lane (r, g) parks the hidden channels of its halo pixels (byte offset of (pixel, channel quad g) in LDS
+        // image 0).  The reference zero-pads h, not x: halo pixels OUTSIDE the image must read as zero in the stencil.
+        // Their image slots are zeroed once per item (below, behind the barrier that frees the image area) and the
+        // lane's stores of every stage go to the junk pixels behind the image instead (like the lanes without a
+        // pixel) - no select per value in the GEMM epilogue.
+        unsigned vq[3];
+        bool inside[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int p = 16 * (wave + 8 * j) + r;
+            const int gy = ty0 - 1 + hr[j], gx = tx0 - 1 + hc[j];
+            inside[j] = pv[j] && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            vq[j] = fb_opaque((unsigned)(PL_OFF + ((inside[j] ? p : FB_NP + r) * FB_PS + 4 * g) * 4));
+        }
+
+        if constexpr (GATE) {
+            // The residual is the tile's own input, already in registers (xr: pixel on the lane, channels in the
+            // registers); project_out's accumulators want it transposed (channel on the lane, 4 pixels in the registers).
+            // The image area is still free: park the 256 interior pixels channel-major there (row stride RT floats = 66
+            // bank slots: the 16 rows a ds_read_b128 lane group touches fall on 16 different slots) and read them back
+            // as accumulator tiles behind one barrier - no second global read of x (PMC reads 2.05x).
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int ip = (hr[j] - 1) * FB_TW + hc[j] - 1;
+                if (pv[j] && hr[j] >= 1 && hr[j] <= FB_TH && hc[j] >= 1 && hc[j] <= FB_TW) {
+                    const unsigned vt = (unsigned)(PL_OFF + (8 * g * RT + ip) * 4);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const unsigned vtk = vt + (unsigned)(32 * ks * RT * 4);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) fb_st<float>(lds, vtk, e * RT * 4, xr[j][ks][e]);
+                    }
+                }
+            }
+        }
         // ------------------------------------------------------------ resident input: LayerNorm + fp16 split
         fb_h8 xh[3][KS], xl[3][KS];
-        bool inside[3];
         float osc[3];                              // per pixel: 1 / (operand scales) of the project_in accumulators
         {
             const float invC = 1.0f / (float)a.C;
             const bool wb = a.ln_mode == IRM_LN_WITHBIAS;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int gy = ty0 - 1 + hr[j], gx = tx0 - 1 + hc[j];
-                inside[j] = pv[j] && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 float v[KS][8];
                 float s = 0.f;
                 int kl[KS];                            // opaque here: otherwise the 24 lane masks are hoisted out of the
@@ -301,23 +357,29 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
 
         FB_T(1);
         __builtin_amdgcn_sched_barrier(0);
-        // project_out accumulators start from (residual + bias) in their own scale (s2 / 16, a power of two: exact)
+        // project_out accumulators start from (residual + bias) in their own scale (s2 / 16, a power of two: exact).
+        // One of the 2 CT tiles lives in LDS between the project_out phases (PARK_OFF, lane-linear): the stencil
+        // phase is 4 registers over the 256 the two waves per SIMD allow, and hipcc's own choice is to spill an
+        // accumulator tile to scratch with its store right in front of the iteration-end vmcnt(0).
         f32x4 acc2[2][CT];
+        const unsigned vpark = fb_opaque((unsigned)(PARK_OFF + threadIdx.x * 16));
         if constexpr (GATE) {
-            const int ox = tx0 + 16 * (wave & 1) + 4 * g, oy0 = ty0 + 2 * (wave >> 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             const float rsc = 1.0f / a.inv_s2;
+            const unsigned vt = (unsigned)(PL_OFF + (r * RT + 64 * (wave >> 1) + 16 * (wave & 1) + 4 * g) * 4);
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 const int co = 16 * c + r;
-                const bool cok = co < a.C && ox < a.W;
                 const float bv = (a.bias2 && co < a.C) ? a.bias2[co] : 0.0f;
+                const unsigned vtc = vt + (unsigned)(16 * c * RT * 4);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const bool ok = cok && oy0 + q < a.H;
-                    const float4 rr = *reinterpret_cast<const float4*>(X + (ok ? (long)co * plane + (long)(oy0 + q) * a.W + ox : 0));
-                    acc2[q][c] = (f32x4){(rr.x + bv) * rsc, (rr.y + bv) * rsc, (rr.z + bv) * rsc, (rr.w + bv) * rsc};
+                    const f32x4 rr = fb_ld<f32x4>(lds, vtc, q * FB_TW * 4);
+                    acc2[q][c] = (f32x4){(rr[0] + bv) * rsc, (rr[1] + bv) * rsc, (rr[2] + bv) * rsc, (rr[3] + bv) * rsc};
                 }
             }
+            fb_st<f32x4>(lds, vpark, 0, acc2[1][CT - 1]);
         }
 
         // One unit of the project_in GEMM of a stage = (16-channel tile hct, k-step ks): the weights are the A operand,
@@ -337,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                 for (int j = 0; j < 3; ++j) {
                     f32x4 h;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = inside[j] ? fmaf(acc1[j][e], osc[j], b1[e]) : 0.f;
+                    for (int e = 0; e < 4; ++e) h[e] = fmaf(acc1[j][e], osc[j], b1[e]);
                     fb_st<f32x4>(lds, vq[j], img * PL_B + hct * 64, h);
                 }
             }
@@ -384,20 +446,29 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
         };
 
         FB_T(2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         FB_T(3);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (pv[j] && !inside[j]) {                 // border tiles only: out-of-image halo pixels read as zero
+                const unsigned vz = (unsigned)(PL_OFF + ((16 * (wave + 8 * j) + r) * FB_PS + 4 * g) * 4);
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                fb_st<f32x4>(lds, vz, 0, z4);
+                fb_st<f32x4>(lds, vz, 64, z4);
+                fb_st<f32x4>(lds, vz, PL_B, z4);
+                fb_st<f32x4>(lds, vz, PL_B + 64, z4);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 2 * KS; ++u) gemm1_unit(u / KS, u % KS, 1, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         FB_T(4);
 
-        fb_h8 Gh[2], Gl[2];
+        fb_u4 Gh[2], Gl[2];                            // packed fp16 pairs: the k-slots of lane (r, g) in project_out's MFMA
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { Gh[q][e] = (_Float16)0.f; Gl[q][e] = (_Float16)0.f; }
+        for (int q = 0; q < 2; ++q) { Gh[q] = (fb_u4){0u, 0u, 0u, 0u}; Gl[q] = (fb_u4){0u, 0u, 0u, 0u}; }
 
         float oprev[2][2][4];
         auto store_stage = [&](int st) {               // !GATE: stage st of the depth-wise outputs (oprev) -> Y
@@ -426,11 +497,13 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             if constexpr (!GATE) { if (it > 0) store_stage(it - 1); }
             if constexpr (more) fb_dma<RECP>(a.rec + (long)(it + 2) * RECF, slots + (par ^ 1) * RECF, wave, lane);
             if (GATE && par == 0 && it > 0) fb_dma<W2P>(a.w2 + (long)(it >> 1) * W2F, w2a, wave, lane);
-            if constexpr (!more && par == 1) {
+            if constexpr (!more && (par == 1 || !GATE)) {
                 // unconditional (the last round re-reads a valid item for nothing): under "if (there is a next item)"
                 // the old values would have to stay alive through every iteration of this item, 72 registers.
-                // (Odd stage counts end on the par == 0 instance, which also holds the first half of the project_out
-                // operands: there the request waits until the iteration is over.)
+                // (GATE with an odd stage count ends on the par == 0 instance, which also holds the first half of the
+                // project_out operands: there the request waits until the iteration is over.  The qkv branch has no
+                // such operands: its last iteration requests the input whatever its parity - round 3; before, the odd
+                // stage counts of C = 96 (9 stages) and C = 48 (5) requested it after the last stencil.)
                 load_x(min(nitem, a.items - 1));
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -501,12 +574,14 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
 #pragma unroll
             for (int q = 0; q < (GATE ? 2 : 0); ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float gx = irm_sat_h(__fmul_rn(fb_gelu1(o[0][q][e]) * o[1][q][e], 0.0625f));
-                    asm volatile("" : "+v"(gx));         // one rounded value for hi and lo (see the input split)
-                    const _Float16 h = (_Float16)gx;
-                    Gh[q][4 * par + e] = h;
-                    Gl[q][4 * par + e] = (_Float16)(gx - (float)h);
+                for (int e = 0; e < 4; e += 2) {
+                    // (the taps and the bias of the second half are pre-scaled by 2^-4 on the host: o[1] = dw(h2) / 16, exact)
+                    const float g0 = irm_sat_h(__fmul_rn(fb_gelu1(o[0][q][e]), o[1][q][e]));
+                    const float g1 = irm_sat_h(__fmul_rn(fb_gelu1(o[0][q][e + 1]), o[1][q][e + 1]));
+                    unsigned hh, ll;
+                    fb_split2(g0, g1, hh, ll);
+                    Gh[q][2 * par + e / 2] = hh;
+                    Gl[q][2 * par + e / 2] = ll;
                 }
 #pragma unroll
             for (int q = 0; q < (GATE ? 2 : 0); ++q) asm volatile("" : "+v"(Gh[q]), "+v"(Gl[q]));
@@ -516,21 +591,22 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 }
+                f32x4 accp = fb_ld<f32x4>(lds, vpark, 0);      // the parked tile (q = 1, c = CT - 1)
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
                     const fb_h8 bh = fb_ld<fb_h8>(lds, vw, W2_OFF + (c * 2) * 1024);
                     const fb_h8 bl = fb_ld<fb_h8>(lds, vw, W2_OFF + (c * 2 + 1) * 1024);
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        acc2[q][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Gl[q], bh, acc2[q][c], 0, 0, 0);
-                        acc2[q][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Gh[q], bl, acc2[q][c], 0, 0, 0);
-                        acc2[q][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Gh[q], bh, acc2[q][c], 0, 0, 0);
+                        f32x4& t = (q == 1 && c == CT - 1) ? accp : acc2[q][c];
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(fb_h8, Gl[q]), bh, t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(fb_h8, Gh[q]), bl, t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(fb_h8, Gh[q]), bh, t, 0, 0, 0);
                     }
                 }
+                fb_st<f32x4>(lds, vpark, 0, accp);
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { Gh[q][e] = (_Float16)0.f; Gl[q][e] = (_Float16)0.f; }
+                for (int q = 0; q < 2; ++q) { Gh[q] = (fb_u4){0u, 0u, 0u, 0u}; Gl[q] = (fb_u4){0u, 0u, 0u, 0u}; }
             }
             // the weight DMAs of this iteration must have landed; the last iteration issued none (only the next
             // item's input, which must NOT be waited for here)
@@ -544,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             int it = 0;
             for (; it + 2 < S; it += 2) { iter(P0, T, it); iter(P1, T, it + 1); }
             if (it + 2 == S) { iter(P0, T, it); FB_T(5); iter(P1, F, it + 1); }
-            else { FB_T(5); iter(P0, F, it); load_x(min(nitem, a.items - 1)); }
+            else { FB_T(5); iter(P0, F, it); if constexpr (GATE) load_x(min(nitem, a.items - 1)); }
             FB_T(6);
         }
 
@@ -557,6 +633,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             int t3 = threadIdx.x;
             asm volatile("" : "+v"(t3));
             const int r = t3 & 15, ox = tx0 + 16 * (wave & 1) + 4 * ((t3 & 63) >> 4), oy0 = ty0 + 2 * (wave >> 1);
+            acc2[1][CT - 1] = fb_ld<f32x4>(lds, vpark, 0);
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 const int co = 16 * c + r;
@@ -583,8 +660,8 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
 
 template <int KS, int CT, bool GATE = true>
 static int gdfn_launch(FusedArgs a, int B, hipStream_t stream) {
-    const size_t lds = ((size_t)2 * FB_PLF + 2 * (KS * 1024 + 512) + (GATE ? CT * 512 : 0)) * sizeof(float);
-    static_assert(((size_t)2 * FB_PLF + 2 * (KS * 1024 + 512) + CT * 512) * sizeof(float) <= 160 * 1024, "LDS");
+    const size_t lds = ((size_t)2 * FB_PLF + 2 * (KS * 1024 + 512) + (GATE ? CT * 512 + 2048 : 0)) * sizeof(float);
+    static_assert(((size_t)2 * FB_PLF + 2 * (KS * 1024 + 512) + CT * 512 + 2048) * sizeof(float) <= 160 * 1024, "LDS");
     static int configured_dev[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return IRM_ELAUNCH;

@@ -86,6 +86,7 @@ struct LnSplitArgs {
 
 template <int KS>
 __global__ __launch_bounds__(256) void ln_split_kernel(LnSplitArgs a) {
+    IRM_KERNEL_ENTRY();
     __shared__ __attribute__((aligned(16))) float lw[KS * 32], lb[KS * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < KS * 32; k += blockDim.x) {
@@ -181,6 +182,7 @@ __device__ __forceinline__ void ps_wait_vmcnt() {
 // (one round, mgroups 1: the K 192 shapes).
 template <int KS, int WP, int CT, int CG, int NW, bool LNF = false>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_ps_kernel(PsArgs a) {
+    IRM_KERNEL_ENTRY();
     constexpr int NS = 4;                          // ring depth
     constexpr int FR = 2 * CT;                     // 1 KiB fragments per stage
     constexpr int DPW = (FR + NW - 1) / NW;        // DMA instructions per wave and stage (duplicates fill the last round)
@@ -517,6 +519,7 @@ __device__ __forceinline__ void gs_apply(const float (&k)[9], const float (&r0)[
 // fragments (256-byte runs); CH 32: 128-byte row segments, whole fragments.
 template <int CH>
 __global__ __launch_bounds__(256) void dwconv3x3_gate_split_kernel(GateSplitArgs a) {
+    IRM_KERNEL_ENTRY();
     constexpr int CGS = 256 / CH, COLS = 4 * CGS;  // column quads / columns per workgroup
     constexpr int PXS = 8 * COLS + 4;              // floats per channel row of the LDS tile [channel][pixel] (+ pad)
     __shared__ __attribute__((aligned(16))) float tile[CH * PXS];
@@ -632,6 +635,7 @@ struct Ps2Args {
 // wave, NW waves.
 template <int NH, int WP, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_ps2_kernel(Ps2Args a) {
+    IRM_KERNEL_ENTRY();
     constexpr int NS = 3, MTS = 12, FR = 2 * MTS, STG = FR * 1024;
     constexpr int DPW = FR / NW;                   // DMA instructions per wave and stage
     constexpr int CG = 2, NG = MTS / CG;           // weight fragments in register groups of 2 tiles, two groups in flight

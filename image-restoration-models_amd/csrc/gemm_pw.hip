@@ -101,6 +101,7 @@ __device__ __forceinline__ void irm_stats_from_acc(const f32x4 (&acc)[PT][CT], i
 
 template <int PT, int CT, bool VEC>
 __global__ __launch_bounds__(256) void gemm_pw_kernel(GemmArgs a) {
+    IRM_KERNEL_ENTRY();
     constexpr int BN = 64 * PT;      // pixels per workgroup
     constexpr int BNP = BN + 16;     // row stride: rows k and k+1 land on disjoint bank halves
     constexpr int BK = 16;           // input channels per stage
@@ -284,6 +285,7 @@ typedef _Float16 irm_h4 __attribute__((ext_vector_type(4)));
 
 template <int PT, int CT, int NS, int LN, bool RES, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
+    IRM_KERNEL_ENTRY();
     constexpr int BN = 64 * PT, BK = 16;            // pixels per workgroup, channels per stage
     constexpr int RPU = 256 / BN;                   // X rows per 1 KiB DMA instruction (PT 2: 2, PT 4: 1)
     constexpr int XS = BK * BN;                 // floats of X per stage

@@ -44,6 +44,7 @@ __device__ __forceinline__ xr_h8 xr_cat(xr_h4 a, xr_h4 b) {
 // split this way the compute waves never wait on memory, the stage barrier is the only hand-over.
 template <int KT, int CT, int NS, int WP, int NPT>
 __global__ __launch_bounds__((NPT / WP + 1) * 64, 1) void gemm_xres_kernel(XresArgs a) {
+    IRM_KERNEL_ENTRY();
     constexpr int NW = NPT / WP;                   // compute waves, WP pixel tiles each
     constexpr int BN = NPT * 16;                   // pixels per workgroup (256 for K <= 96, 128 / 64 for K <= 192 / 384:
                                                    // the resident input is 96 KiB in every case)

@@ -9,6 +9,15 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// First statement of every kernel.  Product build: nothing.  -DIRM_ACQUIRE_ENTRY (diagnostic variant, tools/build_variant.sh):
+// an agent-scope acquire (buffer_inv sc1: this CU's vector L1) on every wave before its first load - the round-3
+// experiment on the two-stream stale read.
+#ifdef IRM_ACQUIRE_ENTRY
+#define IRM_KERNEL_ENTRY() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define IRM_KERNEL_ENTRY() do { } while (0)
+#endif
+
 // activation codes shared by the GEMM / conv epilogues
 #define IRM_ACT_NONE 0
 #define IRM_ACT_RELU 1

@@ -20,6 +20,7 @@
 // [B][R][C] -> [B][C][R] through a padded 32x32 LDS tile
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, long in_bs,
                                                         float* __restrict__ out, long out_bs, int R, int C) {
+    IRM_KERNEL_ENTRY();
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -87,7 +88,8 @@ typedef float sc_v4 __attribute__((ext_vector_type(4)));
 // (v_pk_mul_f32 / v_pk_fma_f32).  Pixel ids travel as one vector load per batch (lane i = step i), three
 // batches ahead; u one load per step, two batches ahead.
 template <int N, int R, bool EMIT>
-__global__ __launch_bounds__(64, (N <= 8 ? 4 : N == 16 ? 3 : 2)) void scan_chunk_kernel(ScanArgs a) {   // (waves per SIMD: caps the
+__global__ __launch_bounds__(64, (N <= 8 ? 4 : N == 16 ? 3 : 2)) void scan_chunk_kernel(ScanArgs a) {
+    IRM_KERNEL_ENTRY();   // (waves per SIMD: caps the
     constexpr int J = R + 2 * N, JV = (J + 63) / 64;                                                    // scheduler's read hoisting)
     constexpr int TU = 8;                                     // time steps per batch
     constexpr int RP = (R + 3) & ~3;                          // LDS row: [dt_raw, padded to 16 bytes | B | C]
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(64, (N <= 8 ? 4 : N == 16 ? 3 : 2)) void scan_chunk
 // group again to emit the initial states.  A workgroup owns 8 states of 64 channels.
 template <int N>
 __global__ __launch_bounds__(1024) void scan_carry_kernel(ScanArgs a) {
+    IRM_KERNEL_ENTRY();
     constexpr int NB = N < 8 ? N : 8, G = 16;
     __shared__ float comp[G][NB + 1][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -278,6 +281,7 @@ __global__ __launch_bounds__(1024) void scan_carry_kernel(ScanArgs a) {
 // per (batch, direction, channel block): ysum[chunk 0] <- sum over chunks (fixed order: 16 interleaved partial
 // sums, four loads in flight each, combined in wave order), so the gate reads one value per channel
 __global__ __launch_bounds__(1024) void ysum_reduce_kernel(float* __restrict__ ysum, int nchunk) {
+    IRM_KERNEL_ENTRY();
     __shared__ float part[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float* p = ysum + (long)blockIdx.x * nchunk * 64 + lane;
@@ -329,6 +333,7 @@ extern "C" int irm_selective_scan_f32(const float* xT, const float* pT, const in
 __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ ysum, const float* __restrict__ gw,
                                                    const float* __restrict__ gb, float* __restrict__ gate, int D,
                                                    int DB, int nchunk, float inv_L) {
+    IRM_KERNEL_ENTRY();
     const int b = blockIdx.y;
     const int e = blockIdx.x * 256 + threadIdx.x;           // e = kq * D + d
     if (e >= 4 * D) return;
@@ -361,6 +366,7 @@ struct CombArgs {
 
 template <int DV, int PW>      // DV = ceil(D / 64) values per lane
 __global__ __launch_bounds__(256) void combine_kernel(CombArgs a) {
+    IRM_KERNEL_ENTRY();
     constexpr int PX = 4 * PW, TS = PX + 1;
     extern __shared__ float tile[];                          // [D][PX + 1]
     const int b = blockIdx.y, p0 = blockIdx.x * PX;

@@ -19,6 +19,7 @@ struct ExtractArgs {
 };
 
 __global__ __launch_bounds__(256) void tile_extract_kernel(ExtractArgs a) {
+    IRM_KERNEL_ENTRY();
     const long total = (long)a.T * a.C * a.ph * a.pw;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
@@ -80,6 +81,7 @@ struct BlendArgs {
 #define BLEND_PER_WG 2048
 
 __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a) {
+    IRM_KERNEL_ENTRY();
     const long total = (long)a.H * a.W * a.Co;
     unsigned long long err = 0;
     const bool albu = a.post_scale != 1.0f || a.post_shift != 0.0f;

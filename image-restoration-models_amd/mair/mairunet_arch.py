@@ -132,6 +132,13 @@ def pack_block(m: VSSBlock) -> dict:
     # the two LayerNorm-prologue GEMMs (in_proj, fc1) also in the hi/lo fp16 order of irm_gemm1x1_f16x3_f32
     split = {} if os.environ.get("IRM_GEMM_EXACT") else dict(
         inp_s=_hip.pack_gemm_weight_split(a.in_proj.weight), fc1_s=_hip.pack_gemm_weight_split(m.ffn.fc1.weight))
+    if split:
+        # round 3: the GEMMs without a LayerNorm prologue too (x_proj, out_proj, fc2: 3.6 of the 15.2 ms of a 256x256
+        # image on the exact f32 MFMA), per layer inside the safe range of the unscaled weight split; their inputs
+        # (silu / out_norm / gelu outputs) take the 2^-4 scaled, saturating split of irm_gemm1x1_f16x3_f32
+        for key, wt in (("xproj_s", a.x_proj_weight.reshape(-1, D)), ("outp_s", a.out_proj.weight), ("fc2_s", m.ffn.fc2.weight)):
+            if _hip.split_is_safe(wt):
+                split[key] = _hip.pack_gemm_weight_split(wt)
     return dict(
         **split,
         inp=_hip.pack_gemm_weight(a.in_proj.weight), inp_b=f32(a.in_proj.bias),
@@ -197,14 +204,15 @@ class MambaHost(nn.Module):
         ops.gemm1x1(w["inp_s" if split else "inp"], x, xz, 2 * D, C, bias=w["inp_b"], stats=stats, lnw=w["ln1w"],
                     lnb=w["ln1b"], ln_mode=ops.LN_WITHBIAS, split=split)
         ops.dwconv3x3(xz[:, :D], w["dw"], xc, bias=w["dw_b"], act=ops.ACT_SILU)
-        ops.gemm1x1(w["xproj"], xc, proj, 4 * J, D)
+        s_xp, s_out, s_fc2 = split and "xproj_s" in w, split and "outp_s" in w, split and "fc2_s" in w
+        ops.gemm1x1(w["xproj_s" if s_xp else "xproj"], xc, proj, 4 * J, D, split=s_xp)
         ops.transpose(xc.view(B, D, L), xT, D, L)
         ops.transpose(proj.view(B, 4 * J, L), pT, 4 * J, L)
         ops.selective_scan(xT, pT, ids, w["dtw"], w["dtb"], w["A"], w["Ds"], yT, state, sdt, ysum, B, L, D, N, R, chunk)
         yn = xc                                          # xc is dead after the transposes: reuse for out_norm output
         ops.losh_combine(ysum, w["gw"], w["gb"], gate, yT, w["onw"], w["onb"], xz[:, D:], yn, B, L, D, nchunk)
-        ops.gemm1x1(w["outp"], yn, x, C, D, res=x, bias=w["outp_b"], res_scale=w["s1"],
-                    stats_out=stats if fuse else None)
+        ops.gemm1x1(w["outp_s" if s_out else "outp"], yn, x, C, D, res=x, bias=w["outp_b"], res_scale=w["s1"],
+                    stats_out=stats if fuse else None, split=s_out)
         # --- x = x * skip_scale2 + fc2(gelu(fc1(LN(x))))     (mairunet_arch.py:62-78, 377)
         h = self._buf("mlp_h", B * hid * L, dev).view(B, hid, H, W)
         if not fuse:
@@ -212,8 +220,8 @@ class MambaHost(nn.Module):
         ops.gemm1x1(w["fc1_s" if split else "fc1"], x, h, hid, C, bias=w["fc1_b"], stats=stats, lnw=w["ln2w"],
                     lnb=w["ln2b"], ln_mode=ops.LN_WITHBIAS, act=ops.ACT_GELU, split=split)
         emit = fuse and want_stats
-        ops.gemm1x1(w["fc2"], h, x, C, hid, res=x, bias=w["fc2_b"], res_scale=w["s2"],
-                    stats_out=stats if emit else None)
+        ops.gemm1x1(w["fc2_s" if s_fc2 else "fc2"], h, x, C, hid, res=x, bias=w["fc2_b"], res_scale=w["s2"],
+                    stats_out=stats if emit else None, split=s_fc2)
         return emit
 
 

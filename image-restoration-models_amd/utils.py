@@ -323,6 +323,11 @@ def tiled_forward_device(model: Module, img_dev: torch.Tensor, patch_size, patch
     if ops.TIMER is not None:
         ops.TIMER.break_chain()                    # the tile extraction above is not a timed launch
     nstreams = min(int(getattr(model, "num_streams", 1)), T)
+    if nstreams > 1 and not os.environ.get("IRM_EXPERIMENTAL_STREAMS"):
+        # EXPERIMENTAL, off in the product: on some GPUs of the pool overlapping forwards were not bit-reproducible
+        # (rare stale read of an in-place updated buffer, cause not established: DESIGN.md section 6)
+        raise ValueError("model.num_streams > 1 is experimental (not bit-reproducible on every GPU, DESIGN.md section 6); "
+                         "set IRM_EXPERIMENTAL_STREAMS=1 to run it")
     if nstreams > 1:
         # independent tile groups on separate HIP streams: one group's HBM-bound kernels overlap the
         # other's MFMA-bound GEMMs; the groups join before the blend

@@ -165,13 +165,13 @@ def test_fullsize_batch_independence_and_determinism(dev, model, frame):
     assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3
 
 
-def test_fullsize_two_streams_and_graph_replay(dev, model, frame, monkeypatch):
-    """The two throughput options of the host side at 1280x720.  HIP-graph replay of the per-batch forward gives the
-    frame of the plain path bit for bit (same launches).  Tile groups on two HIP streams (bench.py's
-    value_two_streams leg) give it up to +-1 in a small fraction of the bytes: the Gram chunk plan follows the batch
-    size (3 instead of 6 tiles per launch), and - measured, cause not found, DESIGN section 6 - overlapping forwards
-    are not bit-reproducible run to run (float tiles differ by <= 1e-3), although every kernel reproduces bit for
-    bit next to a busy neighbour stream (tools/probes/two_stream_*.py)."""
+def test_fullsize_graph_replay_and_experimental_two_streams(dev, model, frame, monkeypatch):
+    """HIP-graph replay of the per-batch forward gives the frame of the plain path bit for bit (same launches).
+    Tile groups on two HIP streams are EXPERIMENTAL (refused without IRM_EXPERIMENTAL_STREAMS=1; not in bench.py's JSON):
+    the Gram chunk plan follows the batch size (3 instead of 6 tiles per launch), so the frame may differ from the
+    one-stream frame by 1 in a few hundred bytes, and on some GPUs of the pool overlapping forwards were not
+    bit-reproducible run to run (cause not established; round 3: four runs bit-identical with and
+    without an agent-scope acquire at every kernel entry - the defect did not show on that GPU at all)."""
     img = torch.from_numpy(frame[0]).to(dev)
     monkeypatch.setenv("IRM_NO_GRAPH", "1")
     base, _ = utils.tiled_forward_device(model, img, PS, OV, pad8=True, max_batch=8)
@@ -185,12 +185,16 @@ def test_fullsize_two_streams_and_graph_replay(dev, model, frame, monkeypatch):
     assert len(model._irm_graphs) == 1
     model.num_streams = 2
     try:
+        with pytest.raises(ValueError):
+            utils.tiled_forward_device(model, img, PS, OV, pad8=True, max_batch=8)
+        monkeypatch.setenv("IRM_EXPERIMENTAL_STREAMS", "1")
         runs = [utils.tiled_forward_device(model, img, PS, OV, pad8=True, max_batch=8)[0].clone() for _ in range(3)]
     finally:
         model.num_streams = 1
     for two in runs:
         diff = (two.int() - base.int()).abs()
-        print(f"two streams vs one: {int((diff > 0).sum())} of {diff.numel()} bytes differ, max {int(diff.max())}")
+        print(f"two streams vs one: {int((diff > 0).sum())} of {diff.numel()} bytes differ, max {int(diff.max())}; "
+              f"equal to the first two-stream run: {bool(torch.equal(two, runs[0]))}")
         assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 5e-3
 
 
