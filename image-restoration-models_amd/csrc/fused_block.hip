@@ -342,15 +342,15 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
+                    for (int e = 0; e < 8; e += 2) {
                         // the product must be ONE rounded fp32 value for both parts: left to the compiler, hi comes
                         // from cvt(fp32 product) and lo from a fused v_fma_mix against cvt(exact product) - they
-                        // differ by an fp16 ulp on double-rounding ties (1e-3 outliers)
-                        float xn = __fmul_rn(v[ks][e], rs);
-                        asm volatile("" : "+v"(xn));
-                        const _Float16 h = (_Float16)xn;
-                        xh[j][ks][e] = h;
-                        xl[j][ks][e] = (_Float16)(xn - (float)h);
+                        // differ by an fp16 ulp on double-rounding ties (1e-3 outliers).  fb_split2 takes the rounded
+                        // products as opaque registers.
+                        unsigned hh, ll;
+                        fb_split2(__fmul_rn(v[ks][e], rs), __fmul_rn(v[ks][e + 1], rs), hh, ll);
+                        reinterpret_cast<unsigned*>(&xh[j][ks])[e / 2] = hh;
+                        reinterpret_cast<unsigned*>(&xl[j][ks])[e / 2] = ll;
                     }
             }
         }

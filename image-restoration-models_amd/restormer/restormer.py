@@ -141,7 +141,7 @@ class Restormer(nn.Module):
         self._split = False
         self._ws_by_stream = {}
         #: tiles of one image processed per forward by the device tiler (utils.tiled_forward_device)
-        self.max_tiles_per_batch = 9
+        self.max_tiles_per_batch = 12     # (two 1280x720 frames: utils.tiled_forward_device_batch)
         self.hip_graph = True      # the tiler replays the per-batch forward from a HIP graph (utils.graphed_forward)
         self._tap = None           # tests: a dict that receives a copy of the `refinement` output (restormer.py:274)
 

@@ -286,15 +286,32 @@ def tiled_forward_device(model: Module, img_dev: torch.Tensor, patch_size, patch
     Nothing here synchronises with the host.  hooks="deblurganv2" selects that model's normalize / pad /
     postprocess (src/deblurganv2/__init__.py:11-28) instead of /255 and the reflect pad to 8.
     """
+    outs = tiled_forward_device_batch(model, [img_dev], patch_size, patch_overlap, pad8, noise_sigma,
+                                      None if target_dev is None else [target_dev], max_batch, keep_tiles, hooks)
+    return outs[0]
+
+
+def tiled_forward_device_batch(model: Module, imgs_dev: list, patch_size, patch_overlap, pad8: bool,
+                               noise_sigma=None, targets_dev: list | None = None, max_batch: int = 8,
+                               keep_tiles: list | None = None, hooks: str | None = None) -> list:
+    """The device pipeline for SEVERAL images of one shape at once (throughput serving; the reference's loop,
+    src/utils.py:353-454, is one image and one tile at a time): the tiles of all images form one batch axis, so the
+    low-resolution levels of the network fill the GPU and every kernel's tail is paid once per batch instead of once per
+    image (Restormer, 1280x720: 53.8 ms for one frame, 52.3 ms per frame for two, tools/bench_batch.py).  Each image is
+    extracted, blended, requantised and scored exactly as in the single-image call - a tile's result does not depend on
+    its batch (tests/test_gpu_fullsize.py) - and the list of (out, sse) pairs is returned in order."""
     norm_mean, norm_inv_std, post_scale, post_shift = 0.0, 1.0, 1.0, 0.0
     pad_mode = "reflect8" if pad8 else "none"
     if hooks == "deblurganv2":
         norm_mean = float(np.float32(0.5) * np.float32(255.0))
         norm_inv_std = float(np.float32(1.0) / (np.float32(0.5) * np.float32(255.0)))
         post_scale, post_shift, pad_mode = 0.5, 1.0, "zero32"
-    h, w, c = img_dev.shape
-    is_u16 = img_dev.dtype in (torch.uint16, torch.int16)
-    dev = img_dev.device
+    img0 = imgs_dev[0]
+    h, w, c = img0.shape
+    if any(tuple(im.shape) != (h, w, c) or im.dtype != img0.dtype for im in imgs_dev):
+        raise ValueError("tiled_forward_device_batch: the images of a batch must share shape and dtype")
+    is_u16 = img0.dtype in (torch.uint16, torch.int16)
+    dev = img0.device
     if patch_size:
         ps = min(patch_size, max(h, w))
         ys, xs = tile_origins(h, ps, patch_overlap), tile_origins(w, ps, patch_overlap)
@@ -310,19 +327,23 @@ def tiled_forward_device(model: Module, img_dev: torch.Tensor, patch_size, patch
         ph, pw = th, tw
     origins = [(y0, x0) for y0 in ys for x0 in xs]
     T = len(origins)
+    K = len(imgs_dev)
     org = torch.tensor(origins, dtype=torch.int32).to(dev, non_blocking=True)
     noise = None
     if noise_sigma is not None:
         np.random.seed(seed=0)                       # utils.py:33: same field for every tile
         noise = torch.from_numpy(np.random.normal(0, noise_sigma / 255., (th, tw, c))).to(dev)
-    tiles = torch.empty(T, c, ph, pw, dtype=torch.float32, device=dev)
-    _hip.call("irm_tile_extract", _hip.ptr(img_dev), int(is_u16), _hip.ptr(org), _hip.ptr(noise),
-              _hip.ptr(tiles), h, w, c, th, tw, ph, pw, T, float(norm_mean), float(norm_inv_std), int(pad_mode == "zero32"))
+    tiles = torch.empty(K * T, c, ph, pw, dtype=torch.float32, device=dev)
+    for k, im in enumerate(imgs_dev):
+        _hip.call("irm_tile_extract", _hip.ptr(im), int(is_u16), _hip.ptr(org), _hip.ptr(noise),
+                  _hip.ptr(tiles[k * T:]), h, w, c, th, tw, ph, pw, T, float(norm_mean), float(norm_inv_std),
+                  int(pad_mode == "zero32"))
     c_out = min(3, c)
     pred = None
     if ops.TIMER is not None:
         ops.TIMER.break_chain()                    # the tile extraction above is not a timed launch
-    nstreams = min(int(getattr(model, "num_streams", 1)), T)
+    NT = K * T
+    nstreams = min(int(getattr(model, "num_streams", 1)), NT)
     if nstreams > 1 and not os.environ.get("IRM_EXPERIMENTAL_STREAMS"):
         # EXPERIMENTAL, off in the product: on some GPUs of the pool overlapping forwards were not bit-reproducible
         # (rare stale read of an in-place updated buffer, cause not established: DESIGN.md section 6)
@@ -334,9 +355,9 @@ def tiled_forward_device(model: Module, img_dev: torch.Tensor, patch_size, patch
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)
-        per = -(-T // nstreams)
+        per = -(-NT // nstreams)
         done, outs = [], []
-        for gi, i in enumerate(range(0, T, per)):
+        for gi, i in enumerate(range(0, NT, per)):
             st = _side_stream(dev, gi)
             st.wait_event(ready)
             with torch.cuda.stream(st):
@@ -347,27 +368,30 @@ def tiled_forward_device(model: Module, img_dev: torch.Tensor, patch_size, patch
                 done.append(ev)
         for ev in done:
             main.wait_event(ev)
-        pred = torch.empty(T, *outs[0][1].shape[1:], dtype=torch.float32, device=dev)
+        pred = torch.empty(NT, *outs[0][1].shape[1:], dtype=torch.float32, device=dev)
         for i, o in outs:
             pred[i:i + o.shape[0]] = o
             o.record_stream(main)
     else:
-        for i in range(0, T, max_batch):
+        for i in range(0, NT, max_batch):
             o = graphed_forward(model, tiles[i:i + max_batch]) if callable(getattr(model, "forward", None)) else model(tiles[i:i + max_batch])
             if pred is None:
-                pred = o if o.shape[0] == T else torch.empty(T, *o.shape[1:], dtype=torch.float32, device=dev)
+                pred = o if o.shape[0] == NT else torch.empty(NT, *o.shape[1:], dtype=torch.float32, device=dev)
             if pred is not o:
                 pred[i:i + o.shape[0]] = o
     if keep_tiles is not None:
         keep_tiles.append(pred[:, :c_out, :th, :tw].clone())
-    out = torch.empty(h, w, c_out, dtype=img_dev.dtype, device=dev)
-    sse = None
-    if target_dev is not None:
-        sse = torch.zeros(1, dtype=torch.int64, device=dev)
-    _hip.call("irm_window_blend", _hip.ptr(pred), _hip.ptr(org), _hip.ptr(_window_on(dev, ps)), _hip.ptr(out),
-              int(is_u16), _hip.ptr(target_dev), _hip.ptr(sse), h, w, c_out, pred.shape[1], th, tw,
-              pred.shape[2], pred.shape[3], ps, T, post_scale, post_shift)
-    return out, sse
+    results = []
+    for k in range(K):
+        out = torch.empty(h, w, c_out, dtype=img0.dtype, device=dev)
+        sse, tgt = None, None
+        if targets_dev is not None and targets_dev[k] is not None:
+            sse, tgt = torch.zeros(1, dtype=torch.int64, device=dev), targets_dev[k]
+        _hip.call("irm_window_blend", _hip.ptr(pred[k * T:]), _hip.ptr(org), _hip.ptr(_window_on(dev, ps)), _hip.ptr(out),
+                  int(is_u16), _hip.ptr(tgt), _hip.ptr(sse), h, w, c_out, pred.shape[1], th, tw,
+                  pred.shape[2], pred.shape[3], ps, T, post_scale, post_shift)
+        results.append((out, sse))
+    return results
 
 
 def run_model_inference(model: Module, input_img: np.ndarray, device: torch.device,

@@ -216,3 +216,28 @@ def test_fullsize_tiler_round_trip_and_oracle(dev, frame):
     assert np.array_equal(got.cpu().numpy(), ref), "device tiler vs numpy oracle at 1280x720"
     want = int(((ref.astype(np.int64) - inp.astype(np.int64)) ** 2).sum())
     assert int(sse.item()) == want, "integer squared error accumulates exactly"
+
+
+def test_fullsize_two_frames_in_one_batch(dev, model, golden):
+    """utils.tiled_forward_device_batch (bench.py's step: the 12 tiles of two 1280x720 frames in one batched forward):
+    every frame equals its single-frame result up to the batch-dependent Gram summation order (+-1 in < 0.1 % of the
+    bytes, PSNR within 0.001 dB), the batched call reproduces bit for bit, and frame 0 stays within the whole-frame
+    golden's bar."""
+    pairs = [synth.synth_image_pair(i, H, W, 3, seed_base=1000, blur=15) for i in range(2)]
+    imgs = [torch.from_numpy(p[0]).to(dev) for p in pairs]
+    tgts = [torch.from_numpy(p[1]).to(dev) for p in pairs]
+    assert model.max_tiles_per_batch >= 12
+    a = utils.tiled_forward_device_batch(model, imgs, PS, OV, pad8=True, targets_dev=tgts, max_batch=model.max_tiles_per_batch)
+    b = utils.tiled_forward_device_batch(model, imgs, PS, OV, pad8=True, targets_dev=tgts, max_batch=model.max_tiles_per_batch)
+    for (o1, s1), (o2, s2) in zip(a, b):
+        assert torch.equal(o1, o2) and int(s1.item()) == int(s2.item())
+    for k in range(2):
+        single, sse = utils.tiled_forward_device(model, imgs[k], PS, OV, pad8=True, target_dev=tgts[k], max_batch=8)
+        diff = (a[k][0].int() - single.int()).abs()
+        p_b = 10 * np.log10(255.0 ** 2 / (float(a[k][1].item()) / single.numel()))
+        p_s = 10 * np.log10(255.0 ** 2 / (float(sse.item()) / single.numel()))
+        print(f"frame {k}: batched vs alone {int((diff > 0).sum())} bytes differ (max {int(diff.max())}), PSNR {p_b:.5f} vs {p_s:.5f}")
+        assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3 and abs(p_b - p_s) < 1e-3
+    g = golden("restormer_fullsize_frame")
+    d0 = np.abs(a[0][0].cpu().numpy().astype(np.int32) - g["pred_u8"].astype(np.int32))
+    assert int(d0.max()) <= 1 and float((d0 > 0).mean()) < 1e-3
