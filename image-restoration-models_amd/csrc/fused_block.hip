@@ -29,7 +29,9 @@ typedef _Float16 fb_h8 __attribute__((ext_vector_type(8)));
 typedef float fb_v2 __attribute__((ext_vector_type(2)));
 typedef unsigned fb_u4 __attribute__((ext_vector_type(4)));
 
+#ifndef FB_INTERLEAVE
 #define FB_INTERLEAVE 3      // plain VALU instructions scheduled behind each MFMA of a GEMM unit
+#endif
 #define FB_TH 8
 #define FB_TW 32
 #define FB_HC (FB_TW + 2)                 // halo columns

@@ -332,10 +332,19 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
     const int TOT = my_chunks * S;
 
     const int xrow = wave * PT * RPU + (lane * 4) / BN;        // + j * RPU
-    const int xcol = min(n0 + (lane * 4) % BN, a.N - 4);
+    // ODD rows of a stage are stored rotated by 16 pixels (the per-lane DMA source is free): the operand reads below
+    // (ds_read_b32, lanes (r, g): row 4 kk + g, pixel r) then put rows g and g + 1 of a 32-lane half on different banks -
+    // unrotated, rows are BN floats = a multiple of 32 banks apart and every read is a 2-way conflict
+    // (tools/probes/lds_conflict.hip patterns 8 / 9: 4.0 -> 2.06 LDS cycles per instruction).  Row parity: PT 2 = two
+    // rows per DMA instruction, lanes 32-63 the odd one; PT 4 = one row per instruction, odd j.
+    const int pc = (lane * 4) % BN;
+    const int xcol = min(n0 + ((pc - (PT == 2 ? 16 * ((lane >> 5) & 1) : 0)) & (BN - 1)), a.N - 4);
+    const int xcol_odd = PT == 2 ? xcol : min(n0 + ((pc - 16) & (BN - 1)), a.N - 4);
     // per-lane source of row xrow; stages and the PT rows of a wave are uniform offsets from it (the VALU
     // shares its datapath with the f32 MFMA: two adds per DMA instead of a clamp and a 64-bit multiply-add)
     const float* xlane = X + (long)xrow * a.N + xcol;
+    const float* xlane_odd = X + (long)xrow * a.N + xcol_odd;
+    const int rdsh = 16 * (g & 1);                             // the same rotation on the read side
     const bool ragged = (a.K % BK) != 0;                       // only then can a row index pass K - 1
 
     auto issue = [&](int it) {
@@ -345,10 +354,12 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
         float* xb = smem + (it % NS) * STG;
         const bool tail = ragged && s == S - 1;
         const float* sbase = xlane + (long)s * BK * a.N;
+        const float* sbase_odd = xlane_odd + (long)s * BK * a.N;
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
-            const float* src = sbase + (long)(j * RPU) * a.N;
-            if (tail) src = X + (long)min(s * BK + xrow + j * RPU, a.K - 1) * a.N + xcol;
+            const bool oddj = PT == 4 && (j & 1);
+            const float* src = (oddj ? sbase_odd : sbase) + (long)(j * RPU) * a.N;
+            if (tail) src = X + (long)min(s * BK + xrow + j * RPU, a.K - 1) * a.N + (oddj ? xcol_odd : xcol);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(xb + (wave * PT + j) * 256),
                                              16, 0, 0);
@@ -401,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
         const float* wb = xb + XS;
         float x0[PT], b0[CT];
 #pragma unroll
-        for (int p = 0; p < PT; ++p) x0[p] = xb[g * BN + wave * 16 * PT + p * 16 + r];
+        for (int p = 0; p < PT; ++p) x0[p] = xb[g * BN + ((wave * 16 * PT + p * 16 + rdsh) & (BN - 1)) + r];
 #pragma unroll
         for (int c = 0; c < CT; ++c) b0[c] = F16 ? 0.0f : wb[c * 4 * 64 + lane];
         if (it + NS - 1 < TOT) issue(it + NS - 1);
@@ -431,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
                 float xv[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const float x = kk == 0 ? x0[p] : xb[(kk * 4 + g) * BN + wave * 16 * PT + p * 16 + r];
+                    const float x = kk == 0 ? x0[p] : xb[(kk * 4 + g) * BN + ((wave * 16 * PT + p * 16 + rdsh) & (BN - 1)) + r];
                     if (LN == IRM_LN_WITHBIAS)
                         xv[kk] = fmaf(fmaf(x, rs[p], nmr[p]), lnp[s * BK + kk * 4 + g], lnp[KP + s * BK + kk * 4 + g]);
                     else if (LN == IRM_LN_BIASFREE) xv[kk] = x * rs[p] * lnp[s * BK + kk * 4 + g];
@@ -473,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
             }
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
-                const float x = kk == 0 ? x0[p] : xb[(kk * 4 + g) * BN + wave * 16 * PT + p * 16 + r];
+                const float x = kk == 0 ? x0[p] : xb[(kk * 4 + g) * BN + ((wave * 16 * PT + p * 16 + rdsh) & (BN - 1)) + r];
                 if (LN == IRM_LN_WITHBIAS) af[p] = fmaf(fmaf(x, rs[p], nmr[p]), wk, bk);
                 else if (LN == IRM_LN_BIASFREE) af[p] = x * rs[p] * wk;
                 else af[p] = x;

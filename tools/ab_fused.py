@@ -18,7 +18,10 @@ def load(path):
     return lib
 
 
-libs = {"base": load(sys.argv[1]), "new": load(sys.argv[2] if len(sys.argv) > 2 else _hip.LIB_PATH)}
+# first argument: the pre-round-3 build (old operand layout); every further library takes the current layout
+libs = {"base": load(sys.argv[1])}
+for pth in (sys.argv[2:] or [_hip.LIB_PATH]):
+    libs["new" if pth == (sys.argv[2:] or [_hip.LIB_PATH])[0] else os.path.basename(pth)] = load(pth)
 SHAPES = [(96, 255, 512, 512, 6), (96, 255, 256, 256, 6), (48, 127, 512, 512, 6)]
 res = {}
 for C, hid, H, W, B in SHAPES:
@@ -27,7 +30,7 @@ for C, hid, H, W, B in SHAPES:
     y = {k: torch.empty_like(x) for k in libs}
     args = (r("a", (2 * hid, C), -.3, .3).to(dev), None, r("b", (2 * hid, 9), -.4, .4), None, r("c", (C, hid), -.3, .3),
             r("d", (C,), .5, 1.5), r("e", (C,), -.2, .2))
-    pk = {"base": _hip.pack_gdfn_fused(*args, gate_prescale=False), "new": _hip.pack_gdfn_fused(*args)}
+    pk = {k: _hip.pack_gdfn_fused(*args, gate_prescale=(k != "base")) for k in libs}
     M = 3 * C
     yq = {k: torch.empty(B, M, H, W, device=dev) for k in libs}
     pq = _hip.pack_qkv_fused(r("qa", (M, C), -.3, .3).to(dev), None, r("qb", (M, 9), -.4, .4), None, r("d", (C,), .5, 1.5),
@@ -54,6 +57,7 @@ for C, hid, H, W, B in SHAPES:
     for op in ("gdfn", "qkv"):
         tb, tn = sorted(times[("base", op)]), sorted(times[("new", op)])
         res[f"{op} C{C} {H}x{W} B{B}"] = dict(base_us_med=tb[len(tb) // 2], new_us_med=tn[len(tn) // 2], base_us_min=tb[0],
-                                              new_us_min=tn[0], ratio=tn[len(tn) // 2] / tb[len(tb) // 2])
+                                              new_us_min=tn[0], ratio=tn[len(tn) // 2] / tb[len(tb) // 2],
+                                              **{k + "_us_med": sorted(times[(k, op)])[len(tb) // 2] for k in libs if k not in ("base", "new")})
     res[f"maxabs base-vs-new C{C} {H}x{W}"] = dict(gdfn=d, qkv=dq)
 print(json.dumps(res, indent=1))
