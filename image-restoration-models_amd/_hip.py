@@ -229,7 +229,7 @@ def plan_presplit(mtiles: int, npt: int, K: int, c0: float | None = None):
     return best[1], best[2], shape
 
 
-def plan_gemm(mtiles: int, blocks: int, options=(9, 8, 6, 4, 3), slots: int = 512, c0: float = 4.0):
+def plan_gemm(mtiles: int, blocks: int, options=(9, 8, 6, 4, 3), slots: int = 512, c0: float = 4.0, res: bool = False):
     """(ct, ygroups) of a 1x1-conv launch: ct output-channel tiles per pass, the passes of a pixel tile split over
     `ygroups` workgroups.  Cost model in tile-pass units: rounds x passes per workgroup x (ct + c0), with
     rounds = ceil(blocks x ygroups / slots) (two ring-kernel workgroups of 57-73 KiB LDS are resident per CU: 512 slots),
@@ -239,12 +239,15 @@ def plan_gemm(mtiles: int, blocks: int, options=(9, 8, 6, 4, 3), slots: int = 51
     best = None
     for ct in options:
         chunks = -(-mtiles // ct)
+        # residual GEMMs with <= 6 tiles per pass run three workgroups per CU (gemm_pw.hip, round 3): 768 slots, each
+        # a third slower while all three are resident
+        sl, slow = (slots * 3 // 2, 1.5) if (res and ct <= 6) else (slots, 1.0)
         for yg in range(1, chunks + 1):
             passes = -(-chunks // yg)
             if (yg - 1) * passes >= chunks:
                 continue                                   # an empty group
-            rounds = -(-(blocks * yg) // slots)
-            cost = rounds * passes * (ct + c0)
+            rounds = -(-(blocks * yg) // sl)
+            cost = rounds * passes * (ct + c0) * slow
             key = (cost, yg, -ct)
             if best is None or key < best[0]:
                 best = (key, ct, yg)

@@ -284,7 +284,7 @@ __device__ __forceinline__ void irm_wait_vmcnt() {
 typedef _Float16 irm_h4 __attribute__((ext_vector_type(4)));
 
 template <int PT, int CT, int NS, int LN, bool RES, bool F16 = false>
-__global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, (PT == 2 && NS == 3) ? 3 : 2) void gemm_ring_kernel(GemmArgs a) {
     IRM_KERNEL_ENTRY();
     constexpr int BN = 64 * PT, BK = 16;            // pixels per workgroup, channels per stage
     constexpr int RPU = 256 / BN;                   // X rows per 1 KiB DMA instruction (PT 2: 2, PT 4: 1)
@@ -553,15 +553,28 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmArgs a) {
     }
 }
 
-template <int PT, int CT, int LN, bool RES, bool F16 = false>
-static int launch_ring(const GemmArgs& a, int B, int ygroups, hipStream_t stream) {
-    constexpr int NS = PT == 2 ? 4 : 3;
+template <int PT, int CT, int NS, int LN, bool RES, bool F16>
+static int launch_ring_ns(const GemmArgs& a, int B, int ygroups, hipStream_t stream) {
     constexpr int BN = 64 * PT;
     const size_t lds = ((size_t)NS * (16 * BN + CT * 256) + 2 * (size_t)a.ksteps * 4) * sizeof(float);
     IRM_ALLOW_BIG_LDS((&gemm_ring_kernel<PT, CT, NS, LN, RES, F16>));
     dim3 grid((a.N + BN - 1) / BN, ygroups, B);
     hipLaunchKernelGGL((gemm_ring_kernel<PT, CT, NS, LN, RES, F16>), grid, dim3(256), lds, stream, a);
     return irm_launch_status();
+}
+
+template <int PT, int CT, int LN, bool RES, bool F16 = false>
+static int launch_ring(const GemmArgs& a, int B, int ygroups, hipStream_t stream) {
+    // Residual GEMMs with up to 6 output tiles per pass and K <= 512 (attention apply, project_out at C <= 192): a 3-deep
+    // ring of 14 KiB stages and <= 168 registers let THREE workgroups share a CU (launch bounds of the kernel), so one
+    // workgroup's store epilogue and the next one's ring prologue overlap a third workgroup's steady state: M = K = 96 at
+    // 6 x 512^2 409 -> 381 us, M = K = 192 at 6 x 128^2 65 -> 57 us, M 192 K 510 129 -> 125 us (round 3,
+    // tools/bench_apply.py; a 5-deep ring at two workgroups had bought nothing in round 2).  Long reductions (K 1021:
+    // 136 -> 144 us) want the deeper ring; 8 / 9 tiles per pass need more registers: both keep two workgroups.
+    if constexpr (PT == 2 && RES && CT <= 6) {
+        if (a.K <= 512) return launch_ring_ns<PT, CT, 3, LN, RES, F16>(a, B, ygroups, stream);
+    }
+    return launch_ring_ns<PT, CT, PT == 2 ? 4 : 3, LN, RES, F16>(a, B, ygroups, stream);
 }
 
 // instantiated combinations: 64-pixel waves (PT 4) only without a residual (the prefetched residual

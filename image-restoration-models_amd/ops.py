@@ -112,7 +112,7 @@ def gemm1x1(wp: torch.Tensor, x: torch.Tensor, y: torch.Tensor, M: int, K: int, 
     if ct is None and ygroups is None and stats_out is None:
         # pixels per workgroup of the kernel that will run: 256 (emulated, no residual) or 128
         bn = 256 if (split and res is None) else 128
-        ct, ygroups = _hip.plan_gemm(mt, -(-N // bn) * B)
+        ct, ygroups = _hip.plan_gemm(mt, -(-N // bn) * B, res=res is not None and K <= 512)
     if ct is None:
         ct = _hip.choose_ct(mt)
     if ygroups is None:
