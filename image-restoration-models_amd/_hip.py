@@ -65,8 +65,10 @@ class HipLibraryError(RuntimeError):
 
 def load():
     """Load libirm_hip.so once; raise HipLibraryError if it is not built."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is None:
+        if os.environ.get("IRM_HIP_LIB"):                # diagnostic: an experiment build of the same ABI (tools/build_variant.sh)
+            LIB_PATH = os.path.abspath(os.environ["IRM_HIP_LIB"])
         if not os.path.exists(LIB_PATH):
             raise HipLibraryError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -571,9 +571,11 @@ static int launch_ring(const GemmArgs& a, int B, int ygroups, hipStream_t stream
     // 6 x 512^2 409 -> 381 us, M = K = 192 at 6 x 128^2 65 -> 57 us, M 192 K 510 129 -> 125 us (round 3,
     // tools/bench_apply.py; a 5-deep ring at two workgroups had bought nothing in round 2).  Long reductions (K 1021:
     // 136 -> 144 us) want the deeper ring; 8 / 9 tiles per pass need more registers: both keep two workgroups.
+#ifndef IRM_NO_RING3                              // (variant builds for A/B: tools/build_variant.sh NAME -DIRM_NO_RING3 gemm_pw.hip)
     if constexpr (PT == 2 && RES && CT <= 6) {
         if (a.K <= 512) return launch_ring_ns<PT, CT, 3, LN, RES, F16>(a, B, ygroups, stream);
     }
+#endif
     return launch_ring_ns<PT, CT, PT == 2 ? 4 : 3, LN, RES, F16>(a, B, ygroups, stream);
 }
 
