@@ -133,14 +133,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16x3_kernel(ConvF16Args a) {
                     const int row = px / CF_HC, col = px - row * CF_HC;
                     const float* rp = reinterpret_cast<const float*>(raw) + (8 * cg) * CF_PLANE + row * 40 + col + 3;
                     cf_h8 hi, lo;
+                    float xs[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float x = irm_sat_h(__fmul_rn(rp[e * CF_PLANE], 0.0625f));
-                        asm volatile("" : "+v"(x));                          // one rounded value for hi and lo (see fused_block.hip)
-                        const _Float16 h = (_Float16)x;
-                        hi[e] = h;
-                        lo[e] = (_Float16)(x - (float)h);
-                    }
+                    for (int e = 0; e < 8; ++e) xs[e] = irm_sat_h(__fmul_rn(rp[e * CF_PLANE], 0.0625f));
+                    irm_split8(xs, hi, lo);                                  // one rounded value for hi and lo (irm_common.h)
                     *reinterpret_cast<cf_h8*>(img + px * CF_PXB + cg * 16) = hi;
                     *reinterpret_cast<cf_h8*>(img + px * CF_PXB + 64 + cg * 16) = lo;
                 }

@@ -93,18 +93,6 @@ __device__ __forceinline__ float fb_gelu1(float x) {
     return fmaf(-u, w, __builtin_amdgcn_fmed3f(x, 0.0f, 3.0e38f));      // (med3: max(x, 0) without fmaxf's canonicalising v_max)
 }
 
-// fp16 hi/lo split of two fp32 values into packed pairs: hi = rn16(x), lo = rn16(x - hi) - the difference is exact in
-// fp32, so v_fma_mix{lo,hi}_f16 (f16 source widened, one rounding of the result) gives exactly the two-step value in
-// one instruction per element instead of cvt + sub + cvt (hipcc does not form it from the source expression).
-__device__ __forceinline__ void fb_split2(float a, float b, unsigned& hi, unsigned& lo) {
-    unsigned h, l;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
-    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
-    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
-    hi = h;
-    lo = l;
-}
-
 // LDS accesses as (per-lane byte offset in a VGPR) + (compile-time immediate < 64 KiB): the offsets are made opaque
 // once, otherwise the compiler materialises one address register per distinct constant beyond the 16-bit DS
 // offset field of the 150 KiB layout and spills them.
@@ -350,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                         // differ by an fp16 ulp on double-rounding ties (1e-3 outliers).  fb_split2 takes the rounded
                         // products as opaque registers.
                         unsigned hh, ll;
-                        fb_split2(__fmul_rn(v[ks][e], rs), __fmul_rn(v[ks][e + 1], rs), hh, ll);
+                        irm_split2(__fmul_rn(v[ks][e], rs), __fmul_rn(v[ks][e + 1], rs), hh, ll);
                         reinterpret_cast<unsigned*>(&xh[j][ks])[e / 2] = hh;
                         reinterpret_cast<unsigned*>(&xl[j][ks])[e / 2] = ll;
                     }
@@ -581,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                     const float g0 = irm_sat_h(__fmul_rn(fb_gelu1(o[0][q][e]), o[1][q][e]));
                     const float g1 = irm_sat_h(__fmul_rn(fb_gelu1(o[0][q][e + 1]), o[1][q][e + 1]));
                     unsigned hh, ll;
-                    fb_split2(g0, g1, hh, ll);
+                    irm_split2(g0, g1, hh, ll);
                     Gh[q][2 * par + e / 2] = hh;
                     Gl[q][2 * par + e / 2] = ll;
                 }

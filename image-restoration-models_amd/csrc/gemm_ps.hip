@@ -57,20 +57,17 @@ __device__ __forceinline__ void ps_ln_pixel(const float (&v)[KS][8], int K, int 
         const float4 b1 = *reinterpret_cast<const float4*>(lb + ks * 32 + 8 * g + 4);
         const float we[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
         const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float ys[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float y;
             if (ln_mode == IRM_LN_WITHBIAS) y = __fmaf_rn(__fmul_rn(__fsub_rn(v[ks][e], mean), rstd), we[e], be[e]);
             else y = __fmul_rn(__fmul_rn(v[ks][e], rstd), we[e]);      // BiasFree: the mean only enters the variance
             // finite for any input (the scale leaves 16x headroom over the typical bound; see _hip.ln_split_scale)
-            y = fminf(fmaxf(y, -65000.0f), 65000.0f);
-            // one opaque fp32 value: hi and lo must be derived from the SAME rounded product (a fused
-            // v_fma_mixlo_f16 would round the exact product instead and break the split on double-rounding ties)
-            asm volatile("" : "+v"(y));
-            const _Float16 hh = (_Float16)y;
-            hi[ks][e] = hh;
-            lo[ks][e] = (_Float16)(y - (float)hh);
+            ys[e] = irm_sat_h(y);
         }
+        // hi and lo from the SAME rounded fp32 value (irm_split2 takes it as an opaque register operand)
+        irm_split8(ys, hi[ks], lo[ks]);
     }
 }
 
@@ -579,14 +576,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_gate_split_kernel(GateSplitArgs
         if (y0 + row >= a.H || x0 + seg * 16 >= a.W) continue;
         const float* src = tile + (8 * g8l) * PXS + row * COLS + seg * 16 + i16;
         ps_h8 h, l;
+        float ys[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float y = fminf(fmaxf(__fmul_rn(src[e * PXS], a.scale), -65000.0f), 65000.0f);
-            asm volatile("" : "+v"(y));            // one rounded fp32 value for both parts (see ln_split_kernel)
-            const _Float16 hh = (_Float16)y;
-            h[e] = hh;
-            l[e] = (_Float16)(y - (float)hh);
-        }
+        for (int e = 0; e < 8; ++e) ys[e] = irm_sat_h(__fmul_rn(src[e * PXS], a.scale));
+        irm_split8(ys, h, l);                      // one rounded fp32 value for both parts (irm_common.h)
         const long pt = (long)b * ptl + (((long)(y0 + row) * a.W + x0 + seg * 16) >> 4);
         _Float16* out = a.gs + ((pt * a.KS + ks) * 2) * 512 + ((g8_0 + g8l) * 16 + i16) * 8;
         *reinterpret_cast<ps_h8*>(out) = h;

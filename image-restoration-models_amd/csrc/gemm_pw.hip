@@ -448,11 +448,7 @@ __global__ __launch_bounds__(256, (PT == 2 && NS == 3) ? 3 : 2) void gemm_ring_k
                     else if (LN == IRM_LN_BIASFREE) xv[kk] = x * rs[p] * lnp[s * BK + kk * 4 + g];
                     else xv[kk] = irm_sat_h(x * 0.0625f);            // not normalised: 2^-4 keeps |x| up to 1e6 inside fp16
                 }
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    ah[p][kk] = (_Float16)xv[kk];
-                    al[p][kk] = (_Float16)(xv[kk] - (float)ah[p][kk]);
-                }
+                irm_split4(xv, ah[p], al[p]);
             }
             irm_h4 bh[CT], bl[CT];
 #pragma unroll

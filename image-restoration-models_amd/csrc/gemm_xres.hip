@@ -136,6 +136,7 @@ __global__ __launch_bounds__((NPT / WP + 1) * 64, 1) void gemm_xres_kernel(XresA
         for (int q = 0; q < NQ; ++q) {
             const int kg = q * NPAR + par, s = kg >> 2, gg = kg & 3;
             xr_h4 h, l;
+            float xn[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = 16 * s + 4 * j + gg;
@@ -143,9 +144,9 @@ __global__ __launch_bounds__((NPT / WP + 1) * 64, 1) void gemm_xres_kernel(XresA
                 if (a.ln_mode == IRM_LN_WITHBIAS) x = fmaf((x - mean) * rstd, lnp[k], lnp[16 * KT + k]);
                 else if (a.ln_mode == IRM_LN_BIASFREE) x = x * rstd * lnp[k];
                 if (k >= a.K) x = 0.0f;
-                h[j] = (_Float16)x;
-                l[j] = (_Float16)(x - (float)h[j]);
+                xn[j] = x;
             }
+            irm_split4(xn, h, l);
             // image of a (stage pair, pixel tile): [hi even stage | hi odd stage | lo even | lo odd], 512 B each
             const int off = (((s >> 1) * NPT + pt) * 4 + (s & 1)) * 128 + (gg * 16 + i) * 2;   // floats
             *reinterpret_cast<xr_h4*>(ah + off) = h;

@@ -105,4 +105,38 @@ __device__ __forceinline__ void irm_st4(float* row, int n, int N, float4 v) {
 // overflow and do not clamp).
 __device__ __forceinline__ float irm_sat_h(float x) { return __builtin_amdgcn_fmed3f(x, -65000.0f, 65000.0f); }
 
+// fp16 hi/lo split of fp32 values that are ALREADY rounded (register operands, opaque to the compiler): hi = rn16(x),
+// lo = rn16(x - hi).  The difference is exact in fp32, so v_fma_mix{lo,hi}_f16 (f16 source widened, one rounding of the
+// result) gives exactly the two-step value: cvt_pk + 2 mix instructions per PAIR instead of 2 x (cvt, cvt back, sub, cvt);
+// hipcc does not form it from the source expression, and left alone it may fuse a preceding multiply into the lo part
+// only (hi from the rounded product, lo from the exact one: 2^-11 outliers on double-rounding ties).
+__device__ __forceinline__ void irm_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    unsigned h, l;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
+    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
+    hi = h;
+    lo = l;
+}
+typedef unsigned irm_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned irm_u4 __attribute__((ext_vector_type(4)));
+template <typename H8>
+__device__ __forceinline__ void irm_split8(const float (&x)[8], H8& hi, H8& lo) {
+    static_assert(sizeof(H8) == 16, "8 halves");
+    irm_u4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { unsigned hh, ll; irm_split2(x[2 * e], x[2 * e + 1], hh, ll); h[e] = hh; l[e] = ll; }
+    hi = __builtin_bit_cast(H8, h);
+    lo = __builtin_bit_cast(H8, l);
+}
+template <typename H4>
+__device__ __forceinline__ void irm_split4(const float (&x)[4], H4& hi, H4& lo) {
+    static_assert(sizeof(H4) == 8, "4 halves");
+    irm_u2 h, l;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { unsigned hh, ll; irm_split2(x[2 * e], x[2 * e + 1], hh, ll); h[e] = hh; l[e] = ll; }
+    hi = __builtin_bit_cast(H4, h);
+    lo = __builtin_bit_cast(H4, l);
+}
+
 static inline bool irm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -406,15 +406,14 @@ __global__ __launch_bounds__(256, 2) void mdta_gram_f16x3_kernel(GramArgs a, con
     auto fragment = [&](const float* rowp, float sc, bool norm, float& nacc, gr_h8& hi, gr_h8& lo) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(rowp + o0);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(rowp + o1);
+        float xs[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float x = e < 4 ? v0[e] : v1[e - 4];
             if (norm) nacc = fmaf(x, x, nacc);
-            const float xs = x * sc;                       // power-of-two factor: exact
-            const _Float16 h = (_Float16)xs;
-            hi[e] = h;
-            lo[e] = (_Float16)(xs - (float)h);
+            xs[e] = x * sc;                                // power-of-two factor: exact
         }
+        irm_split8(xs, hi, lo);
     };
 
 #pragma unroll
