@@ -293,20 +293,25 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
         // ------------------------------------------------------------ resident input: LayerNorm + fp16 split
         fb_h8 xh[3][KS], xl[3][KS];
         float osc[3];                              // per pixel: 1 / (operand scales) of the project_in accumulators
-        {
+        // FULL: C == 32 KS (no channel masks), WBK: -1 = flavour read at run time, 0 = BiasFree, 1 = WithBias.  The common
+        // shapes (C = 96 / 64 / 32) take copies without the ~6 selects per value of the general one (round 3: 830 -> 400
+        // vector instructions per item and wave in this phase).
+        auto ln_phase = [&](auto FULL_, auto WBK_) {
+            constexpr bool FULL = decltype(FULL_)::value;
+            constexpr int WBK = decltype(WBK_)::value;
             const float invC = 1.0f / (float)a.C;
-            const bool wb = a.ln_mode == IRM_LN_WITHBIAS;
+            const bool wb = WBK < 0 ? a.ln_mode == IRM_LN_WITHBIAS : WBK == 1;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 float v[KS][8];
                 float s = 0.f;
                 int kl[KS];                            // opaque here: otherwise the 24 lane masks are hoisted out of the
 #pragma unroll                                         // item loop into scalar registers, which then spill
-                for (int ks = 0; ks < KS; ++ks) { kl[ks] = klim[ks]; asm volatile("" : "+v"(kl[ks])); }
+                for (int ks = 0; ks < KS; ++ks) { kl[ks] = FULL ? 8 : klim[ks]; if (!FULL) asm volatile("" : "+v"(kl[ks])); }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { v[ks][e] = xr[j][ks][e]; s += e < kl[ks] ? v[ks][e] : 0.f; }
+                    for (int e = 0; e < 8; ++e) { v[ks][e] = xr[j][ks][e]; s += (FULL || e < kl[ks]) ? v[ks][e] : 0.f; }
                 s += __shfl_xor(s, 16);
                 s += __shfl_xor(s, 32);
                 const float mean = s * invC;
@@ -316,8 +321,8 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float d = v[ks][e] - mean;
-                        q += e < kl[ks] ? d * d : 0.f;
-                        v[ks][e] = e < kl[ks] ? (wb ? d : v[ks][e]) : 0.f;
+                        q += (FULL || e < kl[ks]) ? d * d : 0.f;
+                        v[ks][e] = (FULL || e < kl[ks]) ? (wb ? d : v[ks][e]) : 0.f;
                     }
                 q += __shfl_xor(q, 16);
                 q += __shfl_xor(q, 32);
@@ -333,15 +338,21 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
-                        // the product must be ONE rounded fp32 value for both parts: left to the compiler, hi comes
-                        // from cvt(fp32 product) and lo from a fused v_fma_mix against cvt(exact product) - they
-                        // differ by an fp16 ulp on double-rounding ties (1e-3 outliers).  fb_split2 takes the rounded
-                        // products as opaque registers.
+                        // the product must be ONE rounded fp32 value for both parts (irm_split2: opaque register operands)
                         unsigned hh, ll;
                         irm_split2(__fmul_rn(v[ks][e], rs), __fmul_rn(v[ks][e + 1], rs), hh, ll);
                         reinterpret_cast<unsigned*>(&xh[j][ks])[e / 2] = hh;
                         reinterpret_cast<unsigned*>(&xl[j][ks])[e / 2] = ll;
                     }
+            }
+        };
+        {
+            const std::true_type T_; const std::false_type F_;
+            if (a.C == 32 * KS) {
+                if (a.ln_mode == IRM_LN_WITHBIAS) ln_phase(T_, std::integral_constant<int, 1>{});
+                else ln_phase(T_, std::integral_constant<int, 0>{});
+            } else {
+                ln_phase(F_, std::integral_constant<int, -1>{});
             }
         }
 

@@ -185,7 +185,10 @@ int irm_dwgemm_f16x3_f32(const float* wp_split, long w_bs, const float* dwp, con
  *     [2 tiles][KS][hi|lo][64 lanes][8 halves]: W1' * s1 split into fp16 hi + lo, W1' = project_in.weight * diag(ln.weight);
  *        tile 0 = gate channels 16 i + m, tile 1 = channels hid + 16 i + m; lane = 16 g + m, half j -> input
  *        channel 32 ks + 8 g + j (zero beyond C / hid; record S: zeros)
- *     [10][32] floats: the 9 depth-wise taps + bias of the channels of stage i - 1 (tile 0 | tile 1) (record 0: zeros)
+ *     [10][32] floats: the 9 depth-wise taps + bias of the channels of stage i - 1 (tile 0 | tile 1) (record 0: zeros);
+ *        irm_gdfn_fused_f16x3_f32 only: the taps AND the bias of tile 1 (the channels hid + ..., the gate's multiplier)
+ *        multiplied by 2^-4 - the kernel computes gelu(dw(h1)) * (dw(h2) / 16), saturates at +-65000 and splits that
+ *        into fp16 hi + lo; inv_s2 carries the factor 16 back
  *     [32] floats: bias of h for stage i = project_in.bias + project_in.weight @ ln.bias;  pad to 512
  *   w2 [ceil(S/2)][CT][hi|lo][64 lanes][8 halves]: project_out.weight * s2 split; lane = 16 g + co, half j of
  *        super-stage T -> gate channel 32 T + 16 (j >> 2) + 4 g + (j & 3)
