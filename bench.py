@@ -1,29 +1,29 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): images/s + PSNR, Restormer motion-deblur
-on 1280x720 GoPro-shaped synthetic uint8 frames, one image per GPU per step.
+on 1280x720 GoPro-shaped synthetic uint8 frames.
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = the whole tiled-patch hot path for ONE frame per rank (reference:
-src/utils.py:353-454 + src/restormer/restormer.py): tile extraction (6 tiles of
-512x512, overlap 96), the batched Restormer forward in libirm_hip.so, the
-Gaussian-window blend + requantisation, and the squared error vs the target.
-Frames are resident in HBM before the timed region; the uint8 result stays on
-the device.  Images are independent units: rank r processes its own frames, no
-data-path collective; PSNR rows are gathered once at the end (RCCL all_gather).
+A step = one pass of the hot path over one batch per rank: TWO frames (--frames-per-step), each through tile
+extraction (6 tiles of 512x512, overlap 96; reference: src/utils.py:353-454), their 12 tiles through ONE batched
+Restormer forward in libirm_hip.so (src/restormer/restormer.py), each frame through the Gaussian-window blend +
+requantisation and the squared error vs its target.  Frames are resident in HBM before the timed region; the
+uint8 results stay on the device.  Images are independent units: rank r processes its own frames, no data-path
+collective; PSNR rows and the ids of failed frames are gathered once at the end (RCCL all_gather).
 
-`python bench.py --gpus N` without a launcher starts its own N ranks (a child
-`python -m torch.distributed.run`, before anything touches a GPU) and exits with
-their status.
+`python bench.py --gpus N` without a launcher starts its own N ranks (a child `python -m torch.distributed.run`,
+before anything touches a GPU) and exits with their status.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
-(the kernel group with the largest share of the kernel time, timed with HIP
-events on the launch stream during the timed steps), `cpu_baseline` (the CPU
-oracle on the host cores over a bounded sample, N=1 only) and, at N=1, two
-reference legs measured in child processes: `value_exact_f32` (every GEMM on the
-f32-input MFMA, IRM_GEMM_EXACT=1) and `value_pcie_inclusive` (the reference-shaped
-get_model_prediction call: numpy uint8 in host memory -> numpy uint8).
+Rank 0 prints ONE JSON line (contract in the task statement): `value` = frames per second over all ranks,
+`ms_per_step` (the two-frame step) and `ms_per_frame`; `roofline` (the kernel group with the largest share of the
+kernel time, HIP events on the launch stream during the timed steps; PMC traffic from the committed passes of this
+command); `step_model` per frame: the reference-decomposition bound, this build's OWN bound (`own_frac`) and
+`hbm_util`; `psnr_cpu / psnr_gpu / abs_dpsnr` of frame 0 against the reference's own CPU run of that frame
+(tests/golden fixture); `failed_image_ids`; `cpu_baseline` (the CPU oracle on the host cores over a bounded sample,
+N=1 only) and, at N=1, two reference legs measured in child processes: `value_exact_f32` (every GEMM on the
+f32-input MFMA, IRM_GEMM_EXACT=1) and `value_pcie_inclusive` (the reference-shaped get_model_prediction call:
+numpy uint8 in host memory -> numpy uint8).
 """
 from __future__ import annotations
 

@@ -517,12 +517,17 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                     constexpr int I = decltype(IC)::value, n = decltype(NC)::value;
                     constexpr int hf = I >> 2, dy = I & 3;
                     constexpr int cf = par * SLOT_B + CF_OFF + hf * 64;
+#ifdef FB_ABLATE_TAPS      // timing-only ablation (wrong results): what the 20 tap reads per stage cost
+                    if constexpr (dy == 0) asm volatile("" : "=v"(KB[0]));
+                    if constexpr (dy < 3) { asm volatile("" : "=v"(K[n][0])); asm volatile("" : "=v"(K[n][1])); asm volatile("" : "=v"(K[n][2])); }
+#else
                     if constexpr (dy == 0) fb_dsr<cf + 9 * 128>(KB[0], vc);
                     if constexpr (dy < 3) {
                         fb_dsr<cf + (dy * 3 + 0) * 128>(K[n][0], vc);
                         fb_dsr<cf + (dy * 3 + 1) * 128>(K[n][1], vc);
                         fb_dsr<cf + (dy * 3 + 2) * 128>(K[n][2], vc);
                     }
+#endif
                     fb_dsr<(dy * FB_HC + 0) * (FB_PS * 4) + hf * 64>(P[n][0], vp);
                     fb_dsr<(dy * FB_HC + 1) * (FB_PS * 4) + hf * 64>(P[n][1], vp);
                     fb_dsr<(dy * FB_HC + 2) * (FB_PS * 4) + hf * 64>(P[n][2], vp);
@@ -543,7 +548,11 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                     if constexpr (!more) loads(fb_ic<I>{}, fb_ic<0>{});
                     // LDS operations issued after the loads of chunk I: the loads of chunk I + 1
                     constexpr int J = I + 1, jdy = J & 3;
+#ifdef FB_ABLATE_TAPS
+                    constexpr int nnext = (more && J < 8) ? 3 +
+#else
                     constexpr int nnext = (more && J < 8) ? 3 + (jdy < 3 ? 3 : 0) + (jdy == 0 ? 1 : 0) +
+#endif
                                                       ((more && J < 2 * KS) ? 2 + (J % KS == KS - 1 ? 1 : 0) : 0) : 0;
                     fb_waitcnt<nnext>();
                     fb_tie(P[c][0], P[c][1], P[c][2]);

@@ -360,8 +360,8 @@ def test_gate_split_gemm_res(dev, M, hid, H, W, B, bias, wg_shape, ch):
                                              (1020, 32, 32, 6, 1, True)])
 def test_ln_gemm_presplit_fused(dev, M, H, W, B, ln, bias):
     """irm_ln_gemm_presplit_f16x3_f32 (LayerNorm + split inside the GEMM's operand load, K = 192) against float64 and against
-    the two-launch pair irm_ln_split_f16 + irm_gemm_presplit_f16x3_f32 (same arithmetic; the two agree to a few fp32 ulps
-    and are equally close to float64), incl. tail workgroups and a sentinel-padded output."""
+    the two-launch pair irm_ln_split_f16 + irm_gemm_presplit_f16x3_f32 (same operands and routine, not bit-identical: measured
+    1.4e-6 ... 3.8e-6 apart, i.e. a few fp32 ulps of the sums, and equally close to float64 - the assertion is dd <= 1e-5), incl. tail workgroups and a sentinel-padded output."""
     K, N = 192, H * W
     big = rnd(f"lfx{M}{H}", (B, K + 2, H, W), -2, 3)
     x = big.to(dev)[:, 1:1 + K]
