@@ -40,6 +40,8 @@ SIGNATURES = {
     "irm_mdta_gram_f16x3_f32": [_P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
     "irm_mdta_finalize_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "irm_mdta_finalize_f16x3_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "irm_mdta_finalize_frag_f16x3_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "irm_attn_gdfn_fused_f16x3_f32": [_P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _L, _I, _F, _F, _F, _I, _I, _I, _I, _I, _P],
     "irm_conv3x3_f32": [_P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "irm_conv3x3_thin_f32": [_P, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "irm_conv3x3_f16x3_f32": [_P, _F, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -401,11 +403,13 @@ def _split_h(t32: torch.Tensor):
     return hi, lo
 
 
-def pack_gdfn_fused(pin_w, pin_b, dw_w, dw_b, pout_w, lnw, lnb, gate_prescale: bool = True):
+def pack_gdfn_fused(pin_w, pin_b, dw_w, dw_b, pout_w, lnw, lnb, gate_prescale: bool = True, kperm: bool = False):
     """Operands of irm_gdfn_fused_f16x3_f32 (include/irm_hip.h) from the reference's parameters
     (FeedForward.project_in / dwconv / project_out and norm2, restormer.py:76-93, 141):
     returns (rec, w2, inv_s1, inv_s2).  The LayerNorm weight is folded into project_in (W diag(w)) and the
-    LayerNorm bias into its bias (W b) in float64, so the kernel normalises only."""
+    LayerNorm bias into its bias (W b) in float64, so the kernel normalises only.
+    kperm: project_in's input channels in the order of irm_attn_gdfn_fused_f16x3_f32 (k-slot 32 ks + 8 g + j <-> channel
+    16 (2 ks + (j >> 2)) + 4 g + (j & 3))."""
     dev = pin_w.device
     pin = pin_w.detach().reshape(pin_w.shape[0], -1).double().cpu()
     pout = pout_w.detach().reshape(pout_w.shape[0], -1).double().cpu()
@@ -425,6 +429,10 @@ def pack_gdfn_fused(pin_w, pin_b, dw_w, dw_b, pout_w, lnw, lnb, gate_prescale: b
     s1 = _pow2_scale(w1)
     w1f = torch.zeros(2, 16 * S, 32 * KS, dtype=torch.float32)
     w1f[:, :hid, :C] = (w1.float() * s1).view(2, hid, C)
+    if kperm:
+        slot = torch.arange(32 * KS)
+        ks_, g_, j_ = slot // 32, (slot % 32) // 8, slot % 8
+        w1f = w1f[:, :, 16 * (2 * ks_ + (j_ >> 2)) + 4 * g_ + (j_ & 3)].contiguous()
     hi, lo = _split_h(w1f)
 
     def arr1(t):      # [hct][S][16 m][KS][4 g][8 j] -> [S][hct][KS][g][m][j]
@@ -459,6 +467,28 @@ def pack_gdfn_fused(pin_w, pin_b, dw_w, dw_b, pout_w, lnw, lnb, gate_prescale: b
     w2pk = torch.stack([arr2(h2), arr2(l2)], dim=2).contiguous()           # [SS][CT][2][g][m][8]
     w2pk = w2pk.view(-1).view(torch.float32)
     return rec.view(-1).to(dev), w2pk.to(dev), 1.0 / (16.0 * s1), 16.0 / s2
+
+
+def pack_mfold_frag(m: torch.Tensor) -> torch.Tensor:
+    """[B][C][C] matrices -> the fragment order irm_mdta_finalize_frag_f16x3_f32 writes (tests, host-side callers):
+    [B][2 KS][KS][hi|lo][lane = 16 g + r][8 halves], lane half e of fragment (t, ks) = M[16 t + r][32 ks + 8 g + e]."""
+    B, C, _ = m.shape
+    KS = (C + 31) // 32
+    mp = torch.zeros(B, 32 * KS, 32 * KS, dtype=torch.float32)
+    mp[:, :C, :C] = m.detach().float().cpu()
+    hi, lo = _split_h(mp)
+
+    def arr(t):       # [B][2KS t][16 r][KS][4 g][8 e] -> [B][t][KS][g][r][e]
+        return t.view(B, 2 * KS, 16, KS, 4, 8).permute(0, 1, 3, 4, 2, 5)
+    return torch.stack([arr(hi), arr(lo)], dim=3).contiguous().view(-1).view(torch.float32).to(m.device)
+
+
+def unpack_mfold_frag(frag: torch.Tensor, B: int, C: int) -> torch.Tensor:
+    """Inverse of pack_mfold_frag: hi + lo as float32 [B][C][C] (tests)."""
+    KS = (C + 31) // 32
+    h = frag.detach().cpu().view(torch.float16).view(B, 2 * KS, KS, 2, 4, 16, 8).float()
+    full = (h[:, :, :, 0] + h[:, :, :, 1]).permute(0, 1, 4, 2, 3, 5).reshape(B, 32 * KS, 32 * KS)
+    return full[:, :C, :C].contiguous()
 
 
 def pack_qkv_fused(qkv_w, qkv_b, dw_w, dw_b, lnw, lnb):

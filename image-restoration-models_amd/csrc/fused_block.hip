@@ -50,6 +50,11 @@ struct FusedArgs {
     int ln_mode; float eps, inv_s1, inv_s2;
     int tiles_x, tiles;                   // tiles per image
     int items, gpx;                       // B * tiles; workgroups per XCD
+    // APPLY (irm_attn_gdfn_fused_f16x3_f32): the attention branch's last step in this kernel's prologue,
+    // x' = x + bias_o + Mfold[b] v, so that x' never reaches HBM
+    const float* V; long v_bs;            // [B][C][H][W] values (after qkv_dwconv)
+    const float* mf; long mf_bs;          // [B][CT][KS][hi|lo][64 lanes][8 halves] folded per-image matrix (mdta_finalize, fragment order)
+    const float* bias_o;                  // [C] attention project_out bias or null
 #ifdef FB_STAMP
     unsigned long long* dbg;
 #endif
@@ -155,8 +160,18 @@ __device__ __forceinline__ void fb_dma(const float* src, float* dst, int wave, i
 // Persistent: one workgroup per CU walks its share of the (image, tile) items; the raw input of the NEXT item is
 // requested during the last stage of the current one (the operand registers of the finished GEMM are free by then),
 // so its HBM latency and the epilogue stores overlap compute, and nothing is paid per tile for workgroup launch.
-template <int KS, int CT, bool GATE>
+//
+// APPLY (GATE only): the tile's input is x' = x + bias_o + Mfold[b] v (restormer.py:131, 147: project_out(attn @ v) + x with
+// the per-image matrix Mfold = W_out blockdiag(softmax) folded by mdta_finalize), computed here for the 340 halo pixels
+// instead of by a 1x1-conv launch that writes x' and this kernel reading it back.  v arrives like x (pixel on the
+// lane, channels 32 ks + 8 g + e in the registers: the B operand of the MFMA, x 2^-4, split into fp16 hi/lo), the
+// matrix fragments of the tile's image by LDS-DMA into the still-free image area; the accumulators start from
+// (x + bias_o) / 16.  The MFMA leaves lane (r, g) with channels 16 t + 4 g + e of pixel r, so in this variant x is
+// loaded in that order: k-slot (ks, g, e) of project_in <-> channel 16 (2 ks + (e >> 2)) + 4 g + (e & 3) (the host
+// packs project_in's columns accordingly; LayerNorm does not care about the order).  C % 16 == 0.
+template <int KS, int CT, bool GATE, bool APPLY = false>
 __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
+    static_assert(!APPLY || GATE, "APPLY is a variant of the GDFN kernel");
     IRM_KERNEL_ENTRY();
     constexpr int W1F = KS * 1024;                 // floats of project_in weights per record (2 tiles x KS x hi/lo x 1 KiB)
     constexpr int RECF = W1F + 512;                // + depth-wise taps [10][32], bias [32], pad
@@ -183,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
     auto item_of = [&](int round) { const int i = round * a.gpx + pos; return i < per ? xcd * per + i : a.items; };
 
 #ifdef FB_STAMP
-    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+    unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
 #endif
     int round = 0;
@@ -209,7 +224,8 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
         }
         int klim[KS];                                  // channel 32 ks + 8 g + e exists <=> e < klim[ks] (compared where used:
 #pragma unroll                                     // 24 lane masks held in scalar registers spill)
-        for (int ks = 0; ks < KS; ++ks) klim[ks] = a.C - 32 * ks - 8 * g;
+        for (int ks = 0; ks < KS; ++ks)
+            klim[ks] = APPLY ? min(8, max(0, 4 * (a.C / 16 - 2 * ks))) : a.C - 32 * ks - 8 * g;
         const unsigned vw = fb_opaque((unsigned)(lane * 16));             // MFMA weight operands: lane-linear 16-byte pieces
         const unsigned vc = fb_opaque((unsigned)(16 * g));                // taps / bias of the lane's channel quad
         const int sp0 = (2 * (wave >> 1)) * FB_HC + 16 * (wave & 1) + r;  // top-left tap in halo coordinates
@@ -237,12 +253,44 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const unsigned off = pix + (unsigned)(8 * min(g2, max((a.C - 32 * ks - 8) / 8, 0)) * plane);
+                    if constexpr (APPLY) {
+                        // x in the order the apply MFMA leaves it: channel 16 (2 ks + (e >> 2)) + 4 g + (e & 3); v in k-slot order
+                        const unsigned offx = pix + (unsigned)(4 * g2 * plane);
+                        const int tmax = a.C / 16 - 1;                 // 16-channel tiles beyond C: a clamped tile (masked)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) xr[j][ks][e] = (X + (long)(32 * ks + e) * plane)[off];
+                        for (int e = 0; e < 8; ++e)
+                            xr[j][ks][e] = (X + (long)(16 * min(2 * ks + (e >> 2), tmax) + (e & 3)) * plane)[offx];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) xr[j][ks][e] = (X + (long)(32 * ks + e) * plane)[off];
+                    }
                 }
             }
         };
 
+        // APPLY: v of an item (k-slot order: channel 32 ks + 8 g + e), requested at the start of the item: kept across the
+        // item boundary beside x (144 registers live around the loop's back edge) the compiler spills a third of x.
+        float vr[APPLY ? 3 : 1][KS][8];
+        auto load_v = [&](int item) {
+            int t2 = threadIdx.x;
+            asm volatile("" : "+v"(t2));
+            const int r2 = t2 & 15, g2 = (t2 & 63) >> 4;
+            const int b = item / a.tiles, tile = item - b * a.tiles;
+            const int ty0 = (tile / a.tiles_x) * FB_TH, tx0 = (tile % a.tiles_x) * FB_TW;
+            const float* V = a.V + (long)b * a.v_bs;
+#pragma unroll
+            for (int j = 0; j < (APPLY ? 3 : 0); ++j) {
+                const int p = 16 * (wave + 8 * j) + r2, ph = p / FB_HC, pc = p - ph * FB_HC;
+                const int gy = ty0 - 1 + ph, gx = tx0 - 1 + pc;
+                const unsigned pix = (unsigned)(min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1));
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const unsigned off = pix + (unsigned)(8 * min(g2, max((a.C - 32 * ks - 8) / 8, 0)) * plane);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vr[j][ks][e] = (V + (long)(32 * ks + e) * plane)[off];
+                }
+            }
+        };
         if (round == 0) load_x(item);
         const int b = item / a.tiles, tile = item - b * a.tiles;
         const int ty0 = (tile / a.tiles_x) * FB_TH, tx0 = (tile % a.tiles_x) * FB_TW;
@@ -270,6 +318,66 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             vq[j] = fb_opaque((unsigned)(PL_OFF + ((inside[j] ? p : FB_NP + r) * FB_PS + 4 * g) * 4));
         }
 
+        if constexpr (APPLY) {
+            // ---------------------------------------------------- x' = x + bias_o + Mfold[b] v  (restormer.py:131, 147)
+            constexpr int MFP = 2 * KS * KS * 2;       // 1 KiB pieces: [2 KS tiles][KS][hi|lo]
+            static_assert(MFP * 1024 <= 2 * PL_B, "the folded matrix must fit the image area");
+            fb_dma<MFP>(a.mf + (long)b * a.mf_bs, smem + PL_OFF / 4, wave, lane);
+            load_v(item);
+            const int nt = a.C / 16;
+            // accumulators = the x registers, in the operand scale of v (2^-4: exact)
+#pragma unroll
+            for (int t = 0; t < 2 * KS; ++t) {
+                f32x4 bo = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias_o && t < nt) bo = *reinterpret_cast<const f32x4*>(a.bias_o + 16 * t + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        xr[j][t >> 1][4 * (t & 1) + e] = t < nt ? (xr[j][t >> 1][4 * (t & 1) + e] + bo[e]) * 0.0625f : 0.f;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            FB_T(8);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                fb_h8 vh[3], vl[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float sv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sv[e] = irm_sat_h(vr[j][ks][e] * 0.0625f);
+                    irm_split8(sv, vh[j], vl[j]);
+                }
+#pragma unroll
+                for (int t = 0; t < 2 * KS; ++t) {
+                    if (t < nt) {
+                        const fb_h8 ah = fb_ld<fb_h8>(lds, vw, PL_OFF + ((t * KS + ks) * 2) * 1024);
+                        const fb_h8 al = fb_ld<fb_h8>(lds, vw, PL_OFF + ((t * KS + ks) * 2 + 1) * 1024);
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            f32x4 acc = {xr[j][t >> 1][4 * (t & 1)], xr[j][t >> 1][4 * (t & 1) + 1],
+                                         xr[j][t >> 1][4 * (t & 1) + 2], xr[j][t >> 1][4 * (t & 1) + 3]};
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, vh[j], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vl[j], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vh[j], acc, 0, 0, 0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) xr[j][t >> 1][4 * (t & 1) + e] = acc[e];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xr[j][ks][e] *= 16.0f;
+            // every wave is done with the matrix before the residual transpose overwrites the image area
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            FB_T(9);
+        }
         if constexpr (GATE) {
             // The residual is the tile's own input, already in registers (xr: pixel on the lane, channels in the
             // registers); project_out's accumulators want it transposed (channel on the lane, 4 pixels in the registers).
@@ -280,12 +388,13 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             for (int j = 0; j < 3; ++j) {
                 const int ip = (hr[j] - 1) * FB_TW + hc[j] - 1;
                 if (pv[j] && hr[j] >= 1 && hr[j] <= FB_TH && hc[j] >= 1 && hc[j] <= FB_TW) {
-                    const unsigned vt = (unsigned)(PL_OFF + (8 * g * RT + ip) * 4);
+                    const unsigned vt = (unsigned)(PL_OFF + ((APPLY ? 4 : 8) * g * RT + ip) * 4);
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         const unsigned vtk = vt + (unsigned)(32 * ks * RT * 4);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) fb_st<float>(lds, vtk, e * RT * 4, xr[j][ks][e]);
+                        for (int e = 0; e < 8; ++e)      // (APPLY: register e holds channel 32 ks + 16 (e >> 2) + 4 g + (e & 3))
+                            fb_st<float>(lds, vtk, (APPLY ? 16 * (e >> 2) + (e & 3) : e) * RT * 4, xr[j][ks][e]);
                     }
                 }
             }
@@ -664,11 +773,11 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
     }
 #ifdef FB_STAMP
     if (threadIdx.x == 0 && a.dbg)
-        for (int i = 0; i < 8; ++i) a.dbg[blockIdx.x * 8 + i] = stamp[i];
+        for (int i = 0; i < 10; ++i) a.dbg[blockIdx.x * 10 + i] = stamp[i];
 #endif
 }
 
-template <int KS, int CT, bool GATE = true>
+template <int KS, int CT, bool GATE = true, bool APPLY = false>
 static int gdfn_launch(FusedArgs a, int B, hipStream_t stream) {
     const size_t lds = ((size_t)2 * FB_PLF + 2 * (KS * 1024 + 512) + (GATE ? CT * 512 + 2048 : 0)) * sizeof(float);
     static_assert(((size_t)2 * FB_PLF + 2 * (KS * 1024 + 512) + CT * 512 + 2048) * sizeof(float) <= 160 * 1024, "LDS");
@@ -676,7 +785,7 @@ static int gdfn_launch(FusedArgs a, int B, hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return IRM_ELAUNCH;
     if (!configured_dev[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lnpw_dw_fused_kernel<KS, CT, GATE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lnpw_dw_fused_kernel<KS, CT, GATE, APPLY>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return IRM_ELAUNCH;
         configured_dev[dev] = 1;
@@ -694,7 +803,7 @@ static int gdfn_launch(FusedArgs a, int B, hipStream_t stream) {
     const int per = (a.items + 7) >> 3;
     a.gpx = (cus_dev[dev] + 7) / 8;
     if (a.gpx > per) a.gpx = per;
-    hipLaunchKernelGGL((lnpw_dw_fused_kernel<KS, CT, GATE>), dim3(a.gpx * 8), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((lnpw_dw_fused_kernel<KS, CT, GATE, APPLY>), dim3(a.gpx * 8), dim3(512), lds, stream, a);
     return irm_launch_status();
 }
 
@@ -709,6 +818,7 @@ extern "C" int irm_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const
     FusedArgs a;
     a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.rec = rec; a.w2 = w2; a.bias2 = bias2;
     a.C = C; a.H = H; a.W = W; a.S = (hid + 15) / 16; a.M = 0; a.ln_mode = ln_mode; a.eps = eps; a.inv_s1 = inv_s1; a.inv_s2 = inv_s2;
+    a.V = nullptr; a.v_bs = 0; a.mf = nullptr; a.mf_bs = 0; a.bias_o = nullptr;
 #ifdef FB_STAMP
     a.dbg = getenv("FB_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FB_DBG_PTR"), nullptr, 0) : nullptr;
 #endif
@@ -725,6 +835,33 @@ extern "C" int irm_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const
     return IRM_EINVAL;
 }
 
+// The attention branch's last step + the GDFN branch: y = x' + GDFN(x'), x' = x + bias_o + Mfold[b] v (header).
+extern "C" int irm_attn_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const float* bias2, const float* x, long x_bs,
+                                             const float* v, long v_bs, const float* mfold_frag, const float* bias_o,
+                                             float* y, long y_bs, int ln_mode, float eps, float inv_s1, float inv_s2, int B,
+                                             int C, int hid, int H, int W, hipStream_t stream) {
+    if (!rec || !w2 || !x || !v || !mfold_frag || !y || x == y || v == y || B <= 0 || C <= 0 || hid <= 0 || H <= 0 || W <= 0)
+        return IRM_EINVAL;
+    if (C > 96 || (C & 15) || (W & 3)) return IRM_EINVAL;
+    if (ln_mode != IRM_LN_WITHBIAS && ln_mode != IRM_LN_BIASFREE) return IRM_EINVAL;
+    if ((x_bs & 3) || (y_bs & 3) || (v_bs & 3) || !irm_aligned16(x) || !irm_aligned16(y) || !irm_aligned16(v) ||
+        !irm_aligned16(rec) || !irm_aligned16(w2) || !irm_aligned16(mfold_frag) || (bias_o && !irm_aligned16(bias_o)))
+        return IRM_EINVAL;
+    FusedArgs a;
+    a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.rec = rec; a.w2 = w2; a.bias2 = bias2;
+    a.C = C; a.H = H; a.W = W; a.S = (hid + 15) / 16; a.M = 0; a.ln_mode = ln_mode; a.eps = eps; a.inv_s1 = inv_s1; a.inv_s2 = inv_s2;
+    const int ks = (C + 31) / 32, ct = (C + 15) / 16;
+    a.V = v; a.v_bs = v_bs; a.mf = mfold_frag; a.mf_bs = (long)2 * ks * ks * 512; a.bias_o = bias_o;
+#ifdef FB_STAMP
+    a.dbg = getenv("FB_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FB_DBG_PTR"), nullptr, 0) : nullptr;
+#endif
+    a.tiles_x = 0; a.tiles = 0;
+    if (ks == 3) return gdfn_launch<3, 6, true, true>(a, B, stream);
+    if (ks == 2) return ct <= 3 ? gdfn_launch<2, 3, true, true>(a, B, stream) : gdfn_launch<2, 4, true, true>(a, B, stream);
+    if (ks == 1) return gdfn_launch<1, 2, true, true>(a, B, stream);
+    return IRM_EINVAL;
+}
+
 extern "C" int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode,
                                           float eps, float inv_s1, int B, int C, int M, int H, int W, hipStream_t stream) {
     if (!rec || !x || !y || x == y || B <= 0 || C <= 0 || M <= 0 || H <= 0 || W <= 0) return IRM_EINVAL;
@@ -734,6 +871,7 @@ extern "C" int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long
     FusedArgs a;
     a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.rec = rec; a.w2 = nullptr; a.bias2 = nullptr;
     a.C = C; a.H = H; a.W = W; a.S = (M + 31) / 32; a.M = M; a.ln_mode = ln_mode; a.eps = eps; a.inv_s1 = inv_s1; a.inv_s2 = 0.f;
+    a.V = nullptr; a.v_bs = 0; a.mf = nullptr; a.mf_bs = 0; a.bias_o = nullptr;
 #ifdef FB_STAMP
     a.dbg = getenv("FB_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FB_DBG_PTR"), nullptr, 0) : nullptr;
 #endif

@@ -607,7 +607,8 @@ struct FinArgs {
     float* mfold;               // [B][mtiles][ksteps][64]
     float* attn;                // optional [B][heads][c][c] (tests) or null
     int C, heads, ksteps;
-    int split;                  // mfold in irm_gemm1x1_f16x3_f32's fp16 hi/lo order instead of packed fp32
+    int split;                  // 1: mfold in irm_gemm1x1_f16x3_f32's fp16 hi/lo order instead of packed fp32;
+                                // 2: as 16x16x32 MFMA fragments [mtile][KS][hi|lo][64 lanes][8 halves] (irm_attn_gdfn_fused_f16x3_f32)
 };
 
 // 16 waves: the softmax rows are chains of dependent cross-lane reductions (latency, not throughput), 6 rows per wave
@@ -676,7 +677,8 @@ __global__ __launch_bounds__(1024) void mdta_finalize_kernel(FinArgs a) {
     }
     // fold with project_out; the output rows are split over gridDim.z workgroups
     const int mtiles = (a.C + 15) / 16;
-    float* mf = a.mfold + (long)b * mtiles * a.ksteps * 64;
+    const int KS32 = (a.C + 31) / 32;
+    float* mf = a.mfold + (a.split == 2 ? (long)b * 2 * KS32 * KS32 * 512 : (long)b * mtiles * a.ksteps * 64);
     const int rows_per = (a.C + gridDim.z - 1) / gridDim.z;
     const int co0 = blockIdx.z * rows_per, co1 = min(co0 + rows_per, a.C);
     // this workgroup's rows of project_out (columns of this head) into LDS: the dot products below then read LDS only
@@ -691,7 +693,14 @@ __global__ __launch_bounds__(1024) void mdta_finalize_kernel(FinArgs a) {
 #pragma unroll 8
         for (int i = 0; i < c; ++i) acc += wrow[i] * G[i * c + j];
         const int kcol = head * c + j;
-        if (a.split) {
+        if (a.split == 2) {
+            // fragment (mtile, 32-channel k-step): lane 16 g + m holds W[16 mtile + m][32 ks + 8 g + e], e = 0..7; hi then lo
+            _Float16* frag = reinterpret_cast<_Float16*>(mf) + ((long)((co >> 4) * KS32 + (kcol >> 5)) * 2) * 512;
+            const int slot = (((kcol & 31) >> 3) * 16 + (co & 15)) * 8 + (kcol & 7);
+            const _Float16 hi = (_Float16)acc;
+            frag[slot] = hi;
+            frag[512 + slot] = (_Float16)(acc - (float)hi);
+        } else if (a.split) {
             // record of (mtile, 16-channel stage): 64 lanes x 4 hi halves, then 64 lanes x 4 lo halves;
             // lane (g, m) slot jj holds W[m][16 stage + 4 jj + g]
             _Float16* rec = reinterpret_cast<_Float16*>(mf + ((long)(co >> 4) * (a.ksteps >> 2) + (kcol >> 4)) * 256);
@@ -731,6 +740,13 @@ extern "C" int irm_mdta_finalize_f32(const float* part, float* gsum, const float
                                      const float* wout, float* mfold, float* attn, int B, int C, int heads,
                                      int nchunk, hipStream_t stream) {
     return mdta_finalize(part, gsum, temperature, wout, mfold, attn, B, C, heads, nchunk, 0, stream);
+}
+
+extern "C" int irm_mdta_finalize_frag_f16x3_f32(const float* part, float* gsum, const float* temperature,
+                                                const float* wout, float* mfold_frag, float* attn, int B, int C,
+                                                int heads, int nchunk, hipStream_t stream) {
+    if (C & 15) return IRM_EINVAL;
+    return mdta_finalize(part, gsum, temperature, wout, mfold_frag, attn, B, C, heads, nchunk, 2, stream);
 }
 
 extern "C" int irm_mdta_finalize_f16x3_f32(const float* part, float* gsum, const float* temperature,

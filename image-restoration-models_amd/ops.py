@@ -285,6 +285,28 @@ def gdfn_fused(pk, x, y, C: int, hid: int, *, ln_mode, bias=None, eps: float = 1
             float(inv_s2), B, C, hid, H, W, tag=f"C{C} hid{hid} {H}x{W} B{B}")
 
 
+def mfold_frag_numel(C: int) -> int:
+    """Floats per image of the folded attention matrix in MFMA fragment order (irm_mdta_finalize_frag_f16x3_f32)."""
+    ks = (C + 31) // 32
+    return 2 * ks * ks * 512
+
+
+def attn_gdfn_fused(pk, x, v, mfold_frag, y, C: int, hid: int, *, ln_mode, bias_o=None, bias=None, eps: float = 1e-5):
+    """y = x' + GDFN(x'), x' = x + bias_o + Mfold[b] v in one kernel (restormer.py:131, 147-148; y is neither x nor v);
+    pk = _hip.pack_gdfn_fused(..., kperm=True), mfold_frag from mdta_fold(..., frag=True)."""
+    _chk(x, "x"), _chk(y, "y"), _chk(v, "v")
+    B, _, H, W = x.shape
+    assert x.data_ptr() != y.data_ptr() and x.shape[1] >= C and y.shape[1] >= C and v.shape[1] >= C and C % 16 == 0
+    assert v.shape[0] == B and v.shape[2:] == x.shape[2:] and mfold_frag.numel() >= B * mfold_frag_numel(C)
+    rec, w2, inv_s1, inv_s2 = pk
+    N = H * W
+    flops = B * N * (2.0 * C * C + 2.0 * 2 * hid * C + 36.0 * hid + 2.0 * hid * C)
+    _launch("attn_gdfn_fused", flops, 4.0 * B * N * 3 * C, "irm_attn_gdfn_fused_f16x3_f32", _hip.ptr(rec), _hip.ptr(w2),
+            _hip.ptr(bias), _hip.ptr(x), _bs(x), _hip.ptr(v), _bs(v), _hip.ptr(mfold_frag), _hip.ptr(bias_o),
+            _hip.ptr(y), _bs(y), int(ln_mode), float(eps), float(inv_s1), float(inv_s2), B, C, hid, H, W,
+            tag=f"C{C} hid{hid} {H}x{W} B{B}")
+
+
 def qkv_dw_fused(pk, x, y, C: int, M: int, *, ln_mode, eps: float = 1e-5):
     """y[:, :M] = dw3x3(W @ LN(x) + b) in one kernel (y is not x); pk = _hip.pack_qkv_fused(...)."""
     _chk(x, "x"), _chk(y, "y")
@@ -323,10 +345,11 @@ def mdta_plan(B: int, C: int, heads: int, N: int):
 
 
 def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, attn=None, split: bool = False,
-              gram_scale=None):
+              gram_scale=None, frag: bool = False):
     """Gram pass + finalize: mfold[b] <- packed(W_out @ blockdiag(softmax(...))) (restormer.py:115-131);
     split: in the fp16 hi/lo order of the emulated GEMM kernels.  gram_scale (_hip.gram_scales): the Gram pass runs
-    as an fp32 emulation on the fp16 matrix cores (c = 48 / 96 channels per head, N % 64 == 0)."""
+    as an fp32 emulation on the fp16 matrix cores (c = 48 / 96 channels per head, N % 64 == 0).  frag: mfold as fp16
+    hi/lo MFMA fragments for attn_gdfn_fused (mfold_frag_numel(C) floats per image, zero-initialised once)."""
     _chk(qkv, "qkv")
     B, _, H, W = qkv.shape
     N = H * W
@@ -342,7 +365,7 @@ def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, att
         _launch("mdta_gram", 2.0 * B * heads * c * c * N, 8.0 * B * C * N, "irm_mdta_gram_f32", _hip.ptr(qkv), _bs(qkv),
                 _hip.ptr(part), B, C, heads, N, chunk, tag=f"C{C} h{heads} N{N} B{B} chunk{chunk}")
     _launch("mdta_finalize", 2.0 * B * C * C * c, 4.0 * B * (heads * nchunk * rec + C * C),
-            "irm_mdta_finalize_f16x3_f32" if split else "irm_mdta_finalize_f32",
+            "irm_mdta_finalize_frag_f16x3_f32" if frag else "irm_mdta_finalize_f16x3_f32" if split else "irm_mdta_finalize_f32",
             _hip.ptr(part), _hip.ptr(gsum), _hip.ptr(temperature), _hip.ptr(wout), _hip.ptr(mfold), _hip.ptr(attn),
             B, C, heads, nchunk, tag=f"C{C} h{heads} nchunk{nchunk} B{B}")
 

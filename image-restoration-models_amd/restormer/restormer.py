@@ -217,6 +217,12 @@ class Restormer(nn.Module):
                                                   m.norm1.w, m.norm1.b),
                         gdfn_f=_hip.pack_gdfn_fused(ff.project_in.weight, ff.project_in.bias, ff.dwconv.weight,
                                                     ff.dwconv.bias, ff.project_out.weight, m.norm2.w, m.norm2.b))
+                    if pk[name]["mfold_split"] and m.dim % 16 == 0:
+                        # attention apply inside the GDFN kernel (irm_attn_gdfn_fused_f16x3_f32): project_in's
+                        # input channels in the order its first MFMA leaves x' in the registers
+                        pk[name]["gdfn_fa"] = _hip.pack_gdfn_fused(
+                            ff.project_in.weight, ff.project_in.bias, ff.dwconv.weight, ff.dwconv.bias,
+                            ff.project_out.weight, m.norm2.w, m.norm2.b, kperm=True)
                 if ops.can_fuse_dw(m.dim, 4):
                     # depth-wise coefficient tables of the fused dw + 1x1 kernel (irm_dwgemm_f32)
                     c, dw, dwb = m.dim, a.qkv_dwconv.weight.reshape(-1, 9), a.qkv_dwconv.bias
@@ -367,6 +373,16 @@ class Restormer(nn.Module):
             mfold = torch.zeros(B * mfold_n, dtype=torch.float32, device=dev)
             ws[("mfold", C, B)] = mfold
         s_fold = w.get("mfold_split", False)
+        if "gdfn_fa" in w and not os.environ.get("IRM_NO_APPLY_FUSE"):
+            # x' = x + project_out(attn @ v) is formed in the GDFN kernel's prologue and never written (:131, 147-148)
+            mfrag = ws.get(("mfold_frag", C, B))
+            if mfrag is None or mfrag.device != dev:
+                mfrag = torch.zeros(B * ops.mfold_frag_numel(C), dtype=torch.float32, device=dev)
+                ws[("mfold_frag", C, B)] = mfrag
+            ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfrag, C, heads, gram_scale=w.get("gram_s"), frag=True)
+            ops.attn_gdfn_fused(w["gdfn_fa"], x, qkv[:, 2 * C:], mfrag, alt, C, hid, ln_mode=blk.norm2.mode,
+                                bias_o=w["wout_b"], bias=w["pout_b"])
+            return alt
         ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=s_fold, gram_scale=w.get("gram_s"))
         ops.gemm1x1(mfold, qkv[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n, split=s_fold)
         ops.gdfn_fused(w["gdfn_f"], x, alt, C, hid, ln_mode=blk.norm2.mode, bias=w["pout_b"])

@@ -203,6 +203,19 @@ int irm_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const float* bia
                              int W, irm_stream_t stream);
 int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode, float eps,
                                float inv_s1, int B, int C, int M, int H, int W, irm_stream_t stream);
+/* irm_attn_gdfn_fused_f16x3_f32 (round 3): the last step of the attention branch inside the GDFN kernel's prologue,
+ *   x' = x + bias_o + Mfold[b] v          (restormer.py:131, 147: project_out(attn @ v) + x, Mfold by irm_mdta_finalize_frag_f16x3_f32)
+ *   y  = x' + project_out(gelu_erf(dw(h)[:hid]) * dw(h)[hid:]) + bias2,  h = project_in(LN(x')) + b      (:76-93, 148)
+ * so that x' is neither written nor read back (replaces irm_gemm1x1_f16x3_f32(Mfold, v, res = x) + irm_gdfn_fused_f16x3_f32).
+ * v: [B][C][H][W] (batch stride v_bs), split behind a fixed 2^-4 scale like every un-normalised GEMM input;
+ * mfold_frag: [B][2 KS][KS][hi|lo][64 lanes][8 halves], KS = ceil(C/32); bias_o: [C] or NULL; C % 16 == 0.
+ * rec as for irm_gdfn_fused_f16x3_f32 except for the order of project_in's input channels: half j of lane 16 g + m of
+ * k-step ks <-> input channel 16 (2 ks + (j >> 2)) + 4 g + (j & 3) (the order in which the MFMA of the first step
+ * leaves x' in the registers; Python: _hip.pack_gdfn_fused(..., kperm=True)). */
+int irm_attn_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const float* bias2, const float* x, long x_bs,
+                                  const float* v, long v_bs, const float* mfold_frag, const float* bias_o, float* y,
+                                  long y_bs, int ln_mode, float eps, float inv_s1, float inv_s2, int B, int C, int hid,
+                                  int H, int W, irm_stream_t stream);
 
 /* MDTA pass 1: per-chunk partial Gram matrices and squared norms.
  * qkv: [B][3C][N] (after qkv_dwconv; q rows [0,C), k rows [C,2C)).
@@ -238,6 +251,12 @@ int irm_mdta_finalize_f32(const float* part, float* gsum, const float* temperatu
 int irm_mdta_finalize_f16x3_f32(const float* part, float* gsum, const float* temperature, const float* wout,
                                 float* mfold_split, float* attn, int B, int C, int heads, int nchunk,
                                 irm_stream_t stream);
+/* Same, with the folded matrix as fp16 hi/lo 16x16x32 MFMA fragments for irm_attn_gdfn_fused_f16x3_f32:
+ * mfold_frag [B][2 KS][KS][hi|lo][64 lanes][8 halves], KS = ceil(C/32), lane 16 g + m half e of fragment (mtile, ks) =
+ * Mfold[16 mtile + m][32 ks + 8 g + e]; zero-initialise once (the slots beyond C are never written).  C % 16 == 0. */
+int irm_mdta_finalize_frag_f16x3_f32(const float* part, float* gsum, const float* temperature, const float* wout,
+                                     float* mfold_frag, float* attn, int B, int C, int heads, int nchunk,
+                                     irm_stream_t stream);
 
 /* Dense 3x3 convolution, stride 1, zero pad 1, implicit GEMM on the f32 MFMA:
  *   v = conv(x)[co] + bias[co]; if relu1: v = max(v,0);

@@ -75,6 +75,60 @@ def test_gdfn_fused(dev, C, hid, H, W, B, ln, bias, ws):
     assert torch.equal(xb.cpu(), big), "input modified"
 
 
+APPLY_CASES = [
+    # C, hid, H, W, B, ln_mode, bias
+    (96, 255, 16, 64, 1, 1, False),
+    (96, 255, 24, 40, 2, 2, True),
+    (48, 127, 16, 32, 2, 1, True),
+    (48, 127, 20, 36, 3, 2, False),
+    (96, 255, 8, 8, 1, 1, True),
+    (32, 85, 12, 20, 1, 1, True),
+    (64, 170, 8, 44, 2, 2, False),
+    (96, 255, 40, 72, 2, 1, True),
+]
+
+
+@pytest.mark.parametrize("C,hid,H,W,B,ln,bias", APPLY_CASES)
+def test_attn_gdfn_fused(dev, C, hid, H, W, B, ln, bias):
+    """x' = x + bias_o + Mfold[b] v, y = x' + GDFN(x') in one kernel (restormer.py:131, 147-148) vs float64."""
+    tag = f"a{C}_{hid}_{H}_{W}_{B}_{ln}"
+    ws = 0.3
+    big = rnd(tag + "x", (B, C + 3, H, W), -1.5, 2.0)
+    vbig = rnd(tag + "v", (B, 3 * C, H, W), -2.0, 2.0)          # v = the last C channels of a qkv buffer
+    mf = rnd(tag + "m", (B, C, C), -0.2, 0.2)                     # per-image folded matrix
+    lnw = rnd(tag + "lw", (C,), 0.5, 1.5)
+    lnb = rnd(tag + "lb", (C,), -0.2, 0.2) if ln == 1 else None
+    pin_w = rnd(tag + "pi", (2 * hid, C), -ws, ws)
+    pout_w = rnd(tag + "po", (C, hid), -ws, ws)
+    dw_w = rnd(tag + "dw", (2 * hid, 9), -0.4, 0.4)
+    pin_b = rnd(tag + "pib", (2 * hid,), -0.3, 0.3) if bias else None
+    dw_b = rnd(tag + "dwb", (2 * hid,), -0.3, 0.3) if bias else None
+    pout_b = rnd(tag + "pob", (C,), -0.3, 0.3) if bias else None
+    bo = rnd(tag + "bo", (C,), -0.3, 0.3) if bias else None
+    x, v = big[:, 1:1 + C], vbig[:, 2 * C:]
+    x1 = x.double() + torch.einsum("bij,bjhw->bihw", mf.double(), v.double())
+    if bo is not None:
+        x1 = x1 + bo.double()[None, :, None, None]
+    ref = gdfn_ref(x1, lnw, lnb, ln, pin_w, pin_b, dw_w, dw_b, pout_w, pout_b)
+    pk = _hip.pack_gdfn_fused(pin_w.to(dev), pin_b, dw_w, dw_b, pout_w, lnw, lnb, kperm=True)
+    frag = _hip.pack_mfold_frag(mf).to(dev)
+    assert torch.equal(_hip.unpack_mfold_frag(frag, B, C), (mf.half().float() + (mf - mf.half().float()).half().float()))
+    xb, vb = big.to(dev), vbig.to(dev)
+    yb = torch.full((B, C + 2, H, W), 7.0, device=dev)
+    ops.attn_gdfn_fused(pk, xb[:, 1:1 + C], vb[:, 2 * C:], frag, yb[:, 2:2 + C], C, hid, ln_mode=ln,
+                        bias_o=None if bo is None else bo.to(dev), bias=None if pout_b is None else pout_b.to(dev))
+    y = yb.cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((y[:, 2:2 + C].double() - ref).abs().max())
+    assert err <= TOL * scale, (err, scale)
+    assert torch.all(y[:, :2] == 7.0), "wrote outside its channel slice"
+    assert torch.equal(xb.cpu(), big) and torch.equal(vb.cpu(), vbig), "input modified"
+    y2 = torch.empty(B, C, H, W, device=dev)
+    ops.attn_gdfn_fused(pk, xb[:, 1:1 + C], vb[:, 2 * C:], frag, y2, C, hid, ln_mode=ln,
+                        bias_o=None if bo is None else bo.to(dev), bias=None if pout_b is None else pout_b.to(dev))
+    assert torch.equal(y2.cpu(), y[:, 2:2 + C]), "not deterministic"
+
+
 def test_gdfn_fused_deterministic(dev):
     C, hid, H, W = 96, 255, 32, 64
     x = rnd("detx", (2, C, H, W), -2, 2).to(dev)

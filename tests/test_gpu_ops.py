@@ -525,6 +525,15 @@ def test_mdta_fold(dev, B, C, heads, H, W):
         ops.gemm1x1(mfold, qg[:, 2 * C:], y2, C, C, w_bs=ops.mfold_numel(C), split=True)
         assert (y2.cpu().double() - ref).abs().max() < TOL
         assert (y2 - y).abs().max() < 2e-5
+    if C % 16 == 0:
+        # ... and as fp16 hi/lo MFMA fragments (irm_attn_gdfn_fused_f16x3_f32's operand): the same matrix, hi + lo
+        mfrag = torch.zeros(B * ops.mfold_frag_numel(C), device=dev)
+        attn2 = torch.empty_like(attn_out)
+        ops.mdta_fold(qg, part, gsum, temp.to(dev), wout.to(dev), mfrag, C, heads, attn=attn2, frag=True)
+        assert torch.equal(attn2, attn_out)
+        mref = torch.stack([wout.double() @ torch.block_diag(*attn_out[i].cpu().double()) for i in range(B)])
+        got = _hip.unpack_mfold_frag(mfrag, B, C).double()
+        assert (got - mref).abs().max() < 1e-6 * max(1.0, float(mref.abs().max()))
 
 
 @pytest.mark.parametrize("B,C,heads,H,W,span", [(2, 48, 1, 16, 24, 1.0), (1, 96, 2, 16, 16, 1.0), (2, 96, 1, 8, 40, 1.0),

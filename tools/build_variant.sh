@@ -1,21 +1,21 @@
 #!/bin/bash
-# usage: tools/build_variant.sh NAME "-DFLAG=.." file.hip [file2.hip ...]  -> tools/variants/libirm_NAME.so
+# usage: tools/build_variant.sh NAME "-DFLAG=.." file.hip [file2.hip ...]  -> tools/vbuild/libirm_NAME.so
 # (experiment builds for A/B timing in one gpurun call; not part of the product build)
 set -e
 cd "$(dirname "$0")/../image-restoration-models_amd/csrc"
 name=$1; flags=$2; shift 2
-mkdir -p ../../tools/variants/obj_$name
+mkdir -p ../../tools/vbuild/obj_$name
 objs=""
 for f in *.hip; do
   o=${f%.hip}.o
   use=$o
   for v in "$@"; do
     if [ "$v" == "$f" ]; then
-      /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-slp-vectorize $flags -c $f -o ../../tools/variants/obj_$name/$o
-      use=../../tools/variants/obj_$name/$o
+      /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-slp-vectorize $flags -c $f -o ../../tools/vbuild/obj_$name/$o
+      use=../../tools/vbuild/obj_$name/$o
     fi
   done
   objs="$objs $use"
 done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs -o ../../tools/variants/libirm_$name.so
-echo built tools/variants/libirm_$name.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs -o ../../tools/vbuild/libirm_$name.so
+echo built tools/vbuild/libirm_$name.so
