@@ -55,6 +55,7 @@ struct FusedArgs {
     const float* V; long v_bs;            // [B][C][H][W] values (after qkv_dwconv)
     const float* mf; long mf_bs;          // [B][CT][KS][hi|lo][64 lanes][8 halves] folded per-image matrix (mdta_finalize, fragment order)
     const float* bias_o;                  // [C] attention project_out bias or null
+    int tm;                               // !GATE: q, k (channels < 2C) stored tile-major [tile][2C][256] inside Y's q, k part
 #ifdef FB_STAMP
     unsigned long long* dbg;
 #endif
@@ -141,6 +142,15 @@ __device__ __forceinline__ void fb_for(F&& f) { fb_for_impl(f, std::make_integer
 #else
 #define FB_T(i) do { } while (0)
 #endif
+
+// input loads of the branch kernels (-DFB_NT: non-temporal, an experiment)
+__device__ __forceinline__ float fb_gld(const float* p) {
+#ifdef FB_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 
 template <int NP>
 __device__ __forceinline__ void fb_dma(const float* src, float* dst, int wave, int lane) {
@@ -259,10 +269,10 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                         const int tmax = a.C / 16 - 1;                 // 16-channel tiles beyond C: a clamped tile (masked)
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            xr[j][ks][e] = (X + (long)(16 * min(2 * ks + (e >> 2), tmax) + (e & 3)) * plane)[offx];
+                            xr[j][ks][e] = fb_gld((X + (long)(16 * min(2 * ks + (e >> 2), tmax) + (e & 3)) * plane) + offx);
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) xr[j][ks][e] = (X + (long)(32 * ks + e) * plane)[off];
+                        for (int e = 0; e < 8; ++e) xr[j][ks][e] = fb_gld((X + (long)(32 * ks + e) * plane) + off);
                     }
                 }
             }
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                 for (int ks = 0; ks < KS; ++ks) {
                     const unsigned off = pix + (unsigned)(8 * min(g2, max((a.C - 32 * ks - 8) / 8, 0)) * plane);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) vr[j][ks][e] = (V + (long)(32 * ks + e) * plane)[off];
+                    for (int e = 0; e < 8; ++e) vr[j][ks][e] = fb_gld((V + (long)(32 * ks + e) * plane) + off);
                 }
             }
         };
@@ -585,6 +595,19 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             int t4 = threadIdx.x;
             asm volatile("" : "+v"(t4));
             const int g = (t4 & 63) >> 4, sy = ty0 + 2 * (wave >> 1), sx = tx0 + 16 * (wave & 1) + (t4 & 15);
+            if (a.tm && 32 * st < 2 * a.C) {
+                // q, k tile-major (irm_qkv_dw_fused_tm_f16x3_f32: full tiles, 2C % 32 == 0): the tile's 2C x 256 floats are one
+                // contiguous block, read back by irm_mdta_gram_tm_f16x3_f32 only
+                float* yt = Y + (long)tile * (2L * a.C * 256) + (long)(32 * st) * 256;
+                const unsigned tvoff = (unsigned)(4 * g * 256 + (2 * (wave >> 1)) * FB_TW + 16 * (wave & 1) + (t4 & 15));
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) yt[tvoff + (16 * hf + e) * 256 + q * FB_TW] = oprev[hf][q][e];
+                return;
+            }
             const unsigned svoff = (unsigned)((4 * g) * plane + (long)sy * a.W + sx);
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
@@ -818,7 +841,7 @@ extern "C" int irm_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const
     FusedArgs a;
     a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.rec = rec; a.w2 = w2; a.bias2 = bias2;
     a.C = C; a.H = H; a.W = W; a.S = (hid + 15) / 16; a.M = 0; a.ln_mode = ln_mode; a.eps = eps; a.inv_s1 = inv_s1; a.inv_s2 = inv_s2;
-    a.V = nullptr; a.v_bs = 0; a.mf = nullptr; a.mf_bs = 0; a.bias_o = nullptr;
+    a.V = nullptr; a.v_bs = 0; a.mf = nullptr; a.mf_bs = 0; a.bias_o = nullptr; a.tm = 0;
 #ifdef FB_STAMP
     a.dbg = getenv("FB_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FB_DBG_PTR"), nullptr, 0) : nullptr;
 #endif
@@ -851,7 +874,7 @@ extern "C" int irm_attn_gdfn_fused_f16x3_f32(const float* rec, const float* w2, 
     a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.rec = rec; a.w2 = w2; a.bias2 = bias2;
     a.C = C; a.H = H; a.W = W; a.S = (hid + 15) / 16; a.M = 0; a.ln_mode = ln_mode; a.eps = eps; a.inv_s1 = inv_s1; a.inv_s2 = inv_s2;
     const int ks = (C + 31) / 32, ct = (C + 15) / 16;
-    a.V = v; a.v_bs = v_bs; a.mf = mfold_frag; a.mf_bs = (long)2 * ks * ks * 512; a.bias_o = bias_o;
+    a.V = v; a.v_bs = v_bs; a.mf = mfold_frag; a.mf_bs = (long)2 * ks * ks * 512; a.bias_o = bias_o; a.tm = 0;
 #ifdef FB_STAMP
     a.dbg = getenv("FB_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FB_DBG_PTR"), nullptr, 0) : nullptr;
 #endif
@@ -862,8 +885,8 @@ extern "C" int irm_attn_gdfn_fused_f16x3_f32(const float* rec, const float* w2, 
     return IRM_EINVAL;
 }
 
-extern "C" int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode,
-                                          float eps, float inv_s1, int B, int C, int M, int H, int W, hipStream_t stream) {
+static int qkv_dw_fused(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode,
+                        float eps, float inv_s1, int B, int C, int M, int H, int W, int tm, hipStream_t stream) {
     if (!rec || !x || !y || x == y || B <= 0 || C <= 0 || M <= 0 || H <= 0 || W <= 0) return IRM_EINVAL;
     if (C > 96 || (W & 3) || (long)M * H * W >= (1L << 30)) return IRM_EINVAL;
     if (ln_mode != IRM_LN_WITHBIAS && ln_mode != IRM_LN_BIASFREE) return IRM_EINVAL;
@@ -871,7 +894,7 @@ extern "C" int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long
     FusedArgs a;
     a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.rec = rec; a.w2 = nullptr; a.bias2 = nullptr;
     a.C = C; a.H = H; a.W = W; a.S = (M + 31) / 32; a.M = M; a.ln_mode = ln_mode; a.eps = eps; a.inv_s1 = inv_s1; a.inv_s2 = 0.f;
-    a.V = nullptr; a.v_bs = 0; a.mf = nullptr; a.mf_bs = 0; a.bias_o = nullptr;
+    a.V = nullptr; a.v_bs = 0; a.mf = nullptr; a.mf_bs = 0; a.bias_o = nullptr; a.tm = tm;
 #ifdef FB_STAMP
     a.dbg = getenv("FB_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FB_DBG_PTR"), nullptr, 0) : nullptr;
 #endif
@@ -882,4 +905,16 @@ extern "C" int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long
         case 1: return gdfn_launch<1, 1, false>(a, B, stream);
     }
     return IRM_EINVAL;
+}
+
+extern "C" int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode,
+                                          float eps, float inv_s1, int B, int C, int M, int H, int W, hipStream_t stream) {
+    return qkv_dw_fused(rec, x, x_bs, y, y_bs, ln_mode, eps, inv_s1, B, C, M, H, W, 0, stream);
+}
+
+// q, k (output channels [0, 2C)) tile-major inside y's q, k part, v planar as before (header).
+extern "C" int irm_qkv_dw_fused_tm_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode,
+                                             float eps, float inv_s1, int B, int C, int H, int W, hipStream_t stream) {
+    if (C <= 0 || (C & 15) || H <= 0 || W <= 0 || (H & 7) || (W & 31)) return IRM_EINVAL;
+    return qkv_dw_fused(rec, x, x_bs, y, y_bs, ln_mode, eps, inv_s1, B, C, 3 * C, H, W, 1, stream);
 }

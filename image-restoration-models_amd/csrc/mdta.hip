@@ -28,6 +28,7 @@ struct GramArgs {
     const float* qkv; long bs;     // [B][3C][N]; q rows [0,C), k rows [C,2C)
     float* part;                   // [B][heads][nchunk][c*c + 2c]
     int C, heads, N, chunk, nchunk;
+    int tm;                        // f16x3 ring kernel: q, k tile-major [B][N / 256][2C][256] inside the q, k part of the buffer
 };
 
 template <int SB, bool VEC>
@@ -357,7 +358,12 @@ __global__ __launch_bounds__(256, 2) void mdta_gram_f16x3_kernel(GramArgs a, con
     const int S = chunk_id < nblocks ? (nblocks - chunk_id + a.nchunk - 1) / a.nchunk : 0;
     const long sstep = (long)a.nchunk * BP;
 #endif
-    const float* base = a.qkv + (long)b * a.bs + nbeg;
+    // Tile-major q, k (a.tm; written by irm_qkv_dw_fused_tm_f16x3_f32): the 256 pixels of an 8 x 32 tile are contiguous per
+    // channel and the 2C channel rows of a tile follow one another - a stage reads 2c row segments 1 KiB apart inside ONE
+    // contiguous 2C KiB block instead of 2c segments a whole plane apart.  Pixel blocks are numbered in tile order; which
+    // pixels a block holds does not matter to the Gram sum as long as q and k agree.
+    const float* base = a.qkv + (long)b * a.bs + (a.tm ? 0 : nbeg);
+    const long rowstride = a.tm ? 256 : a.N;
 
     const float* src[LPS];
 #pragma unroll
@@ -365,13 +371,18 @@ __global__ __launch_bounds__(256, 2) void mdta_gram_f16x3_kernel(GramArgs a, con
         const int row = RPB * (4 * j + wave) + lane / CPR, p = lane % CPR;
         const int rot = gr_rot<T>(row);
         const int ch = row < c ? head * c + row : a.C + head * c + (row - c);
-        src[j] = base + (long)ch * a.N + 4 * ((p - rot) & (CPR - 1));
+        src[j] = base + (long)ch * rowstride + 4 * ((p - rot) & (CPR - 1));
     }
     auto issue = [&](int s) {
         float* dst = smem + (s % NS) * STG + wave * 256;
+        long so = s * sstep;
+        if (a.tm) {
+            const long n0 = (long)nbeg + so;                 // first pixel (tile order) of this stage's block
+            so = (n0 >> 8) * (2L * a.C * 256) + (n0 & 255);
+        }
 #pragma unroll
         for (int j = 0; j < LPS; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + s * sstep),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + so),
                                              (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
         }
     };
@@ -522,7 +533,19 @@ extern "C" int irm_mdta_gram_f16x3_f32(const float* qkv, long bs, const float* s
     const int c = C / heads;
     if ((c != 48 && c != 96) || (N & 63) || (bs & 3) || !irm_aligned16(qkv)) return IRM_EINVAL;
     if ((long)heads * ((N + chunk - 1) / chunk) > 2147483647L) return IRM_EINVAL;
-    GramArgs a{qkv, bs, part, C, heads, N, chunk, (N + chunk - 1) / chunk};
+    GramArgs a{qkv, bs, part, C, heads, N, chunk, (N + chunk - 1) / chunk, 0};
+    return c == 48 ? launch_gram_f16x3<3>(a, scale, B, stream) : launch_gram_f16x3<6>(a, scale, B, stream);
+}
+
+// The same pass over tile-major q, k (header): N % 256 == 0.
+extern "C" int irm_mdta_gram_tm_f16x3_f32(const float* qkv, long bs, const float* scale, float* part, int B, int C,
+                                          int heads, int N, int chunk, hipStream_t stream) {
+    if (!qkv || !scale || !part || B <= 0 || C <= 0 || heads <= 0 || N <= 0 || chunk <= 0) return IRM_EINVAL;
+    if (C % heads || (chunk & 63) || B > 65535) return IRM_EINVAL;
+    const int c = C / heads;
+    if ((c != 48 && c != 96) || (N & 255) || (bs & 3) || !irm_aligned16(qkv)) return IRM_EINVAL;
+    if ((long)heads * ((N + chunk - 1) / chunk) > 2147483647L) return IRM_EINVAL;
+    GramArgs a{qkv, bs, part, C, heads, N, chunk, (N + chunk - 1) / chunk, 1};
     return c == 48 ? launch_gram_f16x3<3>(a, scale, B, stream) : launch_gram_f16x3<6>(a, scale, B, stream);
 }
 
@@ -541,7 +564,7 @@ extern "C" int irm_mdta_gram_f32(const float* qkv, long bs, float* part, int B, 
     if (C % heads || (chunk & 63) || B > 65535) return IRM_EINVAL;
     const int c = C / heads;
     if (c % 16) return IRM_EINVAL;
-    GramArgs a{qkv, bs, part, C, heads, N, chunk, (N + chunk - 1) / chunk};
+    GramArgs a{qkv, bs, part, C, heads, N, chunk, (N + chunk - 1) / chunk, 0};
     const bool aligned = !(N & 3) && !(bs & 3) && irm_aligned16(qkv);
     if (aligned && !(N & 63) && (c == 48 || c == 96) && (long)heads * a.nchunk <= 2147483647L &&
         !irm_probe_set("IRM_GRAM_GENERIC"))

@@ -307,13 +307,25 @@ def attn_gdfn_fused(pk, x, v, mfold_frag, y, C: int, hid: int, *, ln_mode, bias_
             tag=f"C{C} hid{hid} {H}x{W} B{B}")
 
 
-def qkv_dw_fused(pk, x, y, C: int, M: int, *, ln_mode, eps: float = 1e-5):
-    """y[:, :M] = dw3x3(W @ LN(x) + b) in one kernel (y is not x); pk = _hip.pack_qkv_fused(...)."""
+def can_qk_tile_major(C: int, heads: int, H: int, W: int) -> bool:
+    """q, k tile-major (qkv_dw_fused(tm=True) -> mdta_fold(tm=True)): whole 8 x 32 tiles and the f16x3 ring Gram pass."""
+    return C % 16 == 0 and C % heads == 0 and C // heads in (48, 96) and H % 8 == 0 and W % 32 == 0
+
+
+def qkv_dw_fused(pk, x, y, C: int, M: int, *, ln_mode, eps: float = 1e-5, tm: bool = False):
+    """y[:, :M] = dw3x3(W @ LN(x) + b) in one kernel (y is not x); pk = _hip.pack_qkv_fused(...).
+    tm (M = 3C): q, k tile-major inside y[:, :2C] (include/irm_hip.h), for mdta_fold(tm=True) only."""
     _chk(x, "x"), _chk(y, "y")
     B, _, H, W = x.shape
     assert x.data_ptr() != y.data_ptr() and x.shape[1] >= C and y.shape[1] >= M
     rec, inv_s1 = pk
     N = H * W
+    if tm:
+        assert M == 3 * C and y.shape[1] == M and H % 8 == 0 and W % 32 == 0
+        _launch("qkv_dw_fused", B * N * (2.0 * M * C + 18.0 * M), 4.0 * B * N * (C + M), "irm_qkv_dw_fused_tm_f16x3_f32",
+                _hip.ptr(rec), _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y), int(ln_mode), float(eps), float(inv_s1), B, C,
+                H, W, tag=f"C{C} M{M} {H}x{W} B{B} tm")
+        return
     _launch("qkv_dw_fused", B * N * (2.0 * M * C + 18.0 * M), 4.0 * B * N * (C + M), "irm_qkv_dw_fused_f16x3_f32",
             _hip.ptr(rec), _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y), int(ln_mode), float(eps), float(inv_s1), B, C, M,
             H, W, tag=f"C{C} M{M} {H}x{W} B{B}")
@@ -345,7 +357,7 @@ def mdta_plan(B: int, C: int, heads: int, N: int):
 
 
 def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, attn=None, split: bool = False,
-              gram_scale=None, frag: bool = False):
+              gram_scale=None, frag: bool = False, tm: bool = False):
     """Gram pass + finalize: mfold[b] <- packed(W_out @ blockdiag(softmax(...))) (restormer.py:115-131);
     split: in the fp16 hi/lo order of the emulated GEMM kernels.  gram_scale (_hip.gram_scales): the Gram pass runs
     as an fp32 emulation on the fp16 matrix cores (c = 48 / 96 channels per head, N % 64 == 0).  frag: mfold as fp16
@@ -356,9 +368,11 @@ def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, att
     chunk, nchunk, rec = mdta_plan(B, C, heads, N)
     assert part.numel() >= B * heads * nchunk * rec and gsum.numel() >= B * heads * rec
     c = C // heads
-    if gram_scale is not None and c in (48, 96) and N % 64 == 0 and not os.environ.get("IRM_GRAM_EXACT"):
+    assert not tm or (gram_scale is not None and c in (48, 96) and N % 256 == 0), "tile-major q, k: f16x3 ring pass only"
+    if gram_scale is not None and c in (48, 96) and N % 64 == 0 and (tm or not os.environ.get("IRM_GRAM_EXACT")):
         assert gram_scale.numel() == 2 * C and gram_scale.is_contiguous()
-        _launch("mdta_gram_f16x3", 2.0 * B * heads * c * c * N, 8.0 * B * C * N, "irm_mdta_gram_f16x3_f32", _hip.ptr(qkv),
+        _launch("mdta_gram_f16x3", 2.0 * B * heads * c * c * N, 8.0 * B * C * N,
+                "irm_mdta_gram_tm_f16x3_f32" if tm else "irm_mdta_gram_f16x3_f32", _hip.ptr(qkv),
                 _bs(qkv), _hip.ptr(gram_scale), _hip.ptr(part), B, C, heads, N, chunk,
                 tag=f"C{C} h{heads} N{N} B{B} chunk{chunk}")
     else:

@@ -362,7 +362,10 @@ class Restormer(nn.Module):
         dev = x.device
         heads, hid = blk.attn.num_heads, blk.ffn.hidden
         qkv = self._buf("scratch_a", B * 3 * C * N, dev).view(B, 3 * C, H, W)
-        ops.qkv_dw_fused(w["qkv_f"], x, qkv, C, 3 * C, ln_mode=blk.norm1.mode)
+        # q, k tile-major for the Gram pass (its only reader) where the f16x3 ring pass runs on whole tiles
+        tm = ("gram_s" in w and ops.can_qk_tile_major(C, heads, H, W) and not os.environ.get("IRM_GRAM_EXACT")
+              and not os.environ.get("IRM_NO_QK_TM"))
+        ops.qkv_dw_fused(w["qkv_f"], x, qkv, C, 3 * C, ln_mode=blk.norm1.mode, tm=tm)
         _, nchunk, rec = ops.mdta_plan(B, C, heads, N)
         part = self._buf("gram_part", B * heads * nchunk * rec, dev)
         gsum = self._buf("gram_sum", B * heads * rec, dev)
@@ -379,11 +382,11 @@ class Restormer(nn.Module):
             if mfrag is None or mfrag.device != dev:
                 mfrag = torch.zeros(B * ops.mfold_frag_numel(C), dtype=torch.float32, device=dev)
                 ws[("mfold_frag", C, B)] = mfrag
-            ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfrag, C, heads, gram_scale=w.get("gram_s"), frag=True)
+            ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfrag, C, heads, gram_scale=w.get("gram_s"), frag=True, tm=tm)
             ops.attn_gdfn_fused(w["gdfn_fa"], x, qkv[:, 2 * C:], mfrag, alt, C, hid, ln_mode=blk.norm2.mode,
                                 bias_o=w["wout_b"], bias=w["pout_b"])
             return alt
-        ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=s_fold, gram_scale=w.get("gram_s"))
+        ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=s_fold, gram_scale=w.get("gram_s"), tm=tm)
         ops.gemm1x1(mfold, qkv[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n, split=s_fold)
         ops.gdfn_fused(w["gdfn_f"], x, alt, C, hid, ln_mode=blk.norm2.mode, bias=w["pout_b"])
         return alt

@@ -203,6 +203,13 @@ int irm_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const float* bia
                              int W, irm_stream_t stream);
 int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode, float eps,
                                float inv_s1, int B, int C, int M, int H, int W, irm_stream_t stream);
+/* irm_qkv_dw_fused_tm_f16x3_f32 (round 3): M = 3C with q, k (output channels [0, 2C)) stored TILE-MAJOR inside the q, k part
+ * of y - [H/8 * W/32 tiles][2C][256 pixels of the 8 x 32 tile, row-major] per image, the same 2C N floats - and v planar
+ * at channels [2C, 3C) as before.  q, k are read by the Gram pass only (irm_mdta_gram_tm_f16x3_f32): a stage of that pass
+ * then reads 2c row segments 1 KiB apart inside one contiguous block instead of 2c segments a plane apart.
+ * H % 8 == 0, W % 32 == 0, C % 16 == 0. */
+int irm_qkv_dw_fused_tm_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode, float eps,
+                                  float inv_s1, int B, int C, int H, int W, irm_stream_t stream);
 /* irm_attn_gdfn_fused_f16x3_f32 (round 3): the last step of the attention branch inside the GDFN kernel's prologue,
  *   x' = x + bias_o + Mfold[b] v          (restormer.py:131, 147: project_out(attn @ v) + x, Mfold by irm_mdta_finalize_frag_f16x3_f32)
  *   y  = x' + project_out(gelu_erf(dw(h)[:hid]) * dw(h)[hid:]) + bias2,  h = project_in(LN(x')) + b      (:76-93, 148)
@@ -234,6 +241,9 @@ int irm_mdta_gram_f32(const float* qkv, long bs, float* part, int B, int C, int 
  * side: gram_scales); without such a bound (BiasFree LayerNorm) irm_mdta_gram_f32 is the entry point to use.
  * c in {48, 96}, N % 64 == 0, chunk % 64 == 0, 16-byte aligned rows; same partial records as irm_mdta_gram_f32. */
 int irm_mdta_gram_f16x3_f32(const float* qkv, long bs, const float* scale, float* part, int B, int C, int heads, int N,
+                            int chunk, irm_stream_t stream);
+/* The same pass over q, k in the tile-major order of irm_qkv_dw_fused_tm_f16x3_f32 (N % 256 == 0; v is not read). */
+int irm_mdta_gram_tm_f16x3_f32(const float* qkv, long bs, const float* scale, float* part, int B, int C, int heads, int N,
                             int chunk, irm_stream_t stream);
 
 /* MDTA pass 2: reduce the partials (gsum: workspace [B][heads][c*c+2c]),

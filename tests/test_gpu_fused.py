@@ -189,6 +189,37 @@ def test_qkv_dw_fused(dev, C, H, W, B, ln, bias):
     assert torch.all(y[:, 0] == 7.0) and torch.all(y[:, M + 1] == 7.0), "wrote outside its channel slice"
 
 
+@pytest.mark.parametrize("C,heads,H,W,B", [(96, 1, 16, 64, 2), (96, 2, 24, 32, 1), (48, 1, 8, 96, 3), (96, 1, 40, 64, 1)])
+def test_qk_tile_major_chain(dev, C, heads, H, W, B):
+    """qkv_dw_fused(tm) + Gram pass (tm): q, k tile-major [tile][2C][256] - v, the attention matrix and the folded matrix
+    as with planar q, k (the Gram sum runs over the same pixels in another order: a few ulps)."""
+    tag = f"tm{C}_{heads}_{H}_{W}"
+    M, N = 3 * C, H * W
+    x = rnd(tag + "x", (B, C, H, W), -1.5, 2.0).to(dev)
+    lnw, lnb = rnd(tag + "lw", (C,), 0.5, 1.5), rnd(tag + "lb", (C,), -0.2, 0.2)
+    w, dw_w = rnd(tag + "w", (M, C), -0.3, 0.3), rnd(tag + "dw", (M, 9), -0.4, 0.4)
+    pk = _hip.pack_qkv_fused(w.to(dev), None, dw_w, None, lnw, lnb)
+    gs = _hip.gram_scales(w.view(M, C, 1, 1), None, dw_w.view(M, 1, 3, 3), None, lnw, lnb, True).to(dev)
+    temp, wout = rnd(tag + "t", (heads,), 2.0, 6.0).to(dev), rnd(tag + "wo", (C, C), -0.3, 0.3).to(dev)
+    res = []
+    for tm in (False, True):
+        qkv = torch.full((B, M, H, W), 7.0, device=dev)
+        ops.qkv_dw_fused(pk, x, qkv, C, M, ln_mode=1, tm=tm)
+        _, nchunk, rec = ops.mdta_plan(B, C, heads, N)
+        part = torch.full((B * heads * nchunk * rec,), float("nan"), device=dev)
+        gsum = torch.empty(B * heads * rec, device=dev)
+        mfold = torch.zeros(B * ops.mfold_numel(C), device=dev)
+        attn = torch.empty(B, heads, C // heads, C // heads, device=dev)
+        ops.mdta_fold(qkv, part, gsum, temp, wout, mfold, C, heads, attn=attn, gram_scale=gs, tm=tm)
+        res.append((qkv.cpu(), attn.cpu(), mfold.cpu()))
+    (q0, a0, m0), (q1, a1, m1) = res
+    assert torch.equal(q0[:, 2 * C:], q1[:, 2 * C:]), "v must not depend on the q, k layout"
+    # the tile-major block of tile (ty, tx) holds channel ch of pixels (8 ty + r, 32 tx + c) at [ch][32 r + c]
+    back = q1[:, :2 * C].reshape(B, H // 8, W // 32, 2 * C, 8, 32).permute(0, 3, 1, 4, 2, 5).reshape(B, 2 * C, H, W)
+    assert torch.equal(back, q0[:, :2 * C]), "tile-major q, k are not a permutation of the planar ones"
+    assert float((a0 - a1).abs().max()) <= 2e-6 and float((m0 - m1).abs().max()) <= 2e-6
+
+
 def _logu(name, shape, lo, hi):
     """log-uniform magnitudes in [lo, hi] with random signs (trained checkpoints: weights over many decades)."""
     u = rnd(name, shape, 0.0, 1.0)

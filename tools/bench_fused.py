@@ -9,6 +9,8 @@ if "--lib" in sys.argv:
     _hip.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 dev = torch.device("cuda:0")
 SHAPES = [(96, 255, 512, 512, 6), (96, 255, 256, 256, 6), (48, 127, 512, 512, 6)]
+if "--locality" in sys.argv:       # same tiles, per-plane contiguous tile interiors (8 rows x 32 px = 1 KiB): what DRAM page locality is worth
+    SHAPES = [(96, 255, 512, 512, 6), (96, 255, 8192, 32, 6), (96, 255, 2048, 128, 6), (48, 127, 512, 512, 6), (48, 127, 8192, 32, 6)]
 res = {}
 for C, hid, H, W, B in SHAPES:
     r = lambda n, s, lo=-1., hi=1.: synth.uniform(5, n, s, lo, hi)
