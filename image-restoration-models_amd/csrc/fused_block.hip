@@ -56,6 +56,10 @@ struct FusedArgs {
     const float* mf; long mf_bs;          // [B][CT][KS][hi|lo][64 lanes][8 halves] folded per-image matrix (mdta_finalize, fragment order)
     const float* bias_o;                  // [C] attention project_out bias or null
     int tm;                               // !GATE: q, k (channels < 2C) stored tile-major [tile][2C][256] inside Y's q, k part
+    // Tile-major activations between the kernels of a stage (whole 8 x 32 tiles): element (channel, y, x) of an image at
+    // ((y >> 3) tiles_x + (x >> 5)) (Cb 256) + channel 256 + (y & 7) 32 + (x & 31), Cb = channels of that tensor - a tile's
+    // pixels of all channels are ONE contiguous block (the stores of an item, and the reads of its interior, stay inside it).
+    int x_tm, v_tm, y_tm;                 // X; V (APPLY input / !GATE output channels >= 2C); Y (GATE output)
 #ifdef FB_STAMP
     unsigned long long* dbg;
 #endif
@@ -255,11 +259,13 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             const int b = item / a.tiles, tile = item - b * a.tiles;
             const int ty0 = (tile / a.tiles_x) * FB_TH, tx0 = (tile % a.tiles_x) * FB_TW;
             const float* X = a.X + (long)b * a.x_bs;
+            const long plane = a.x_tm ? 256 : (long)a.H * a.W;          // (channel stride of x)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int p = 16 * (wave + 8 * j) + r2, ph = p / FB_HC, pc = p - ph * FB_HC;
-                const int gy = ty0 - 1 + ph, gx = tx0 - 1 + pc;
-                const unsigned pix = (unsigned)(min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1));
+                const int gy = min(max(ty0 - 1 + ph, 0), a.H - 1), gx = min(max(tx0 - 1 + pc, 0), a.W - 1);
+                const unsigned pix = a.x_tm ? (unsigned)(((gy >> 3) * a.tiles_x + (gx >> 5)) * (a.C * 256) + (gy & 7) * FB_TW + (gx & 31))
+                                            : (unsigned)(gy * a.W + gx);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const unsigned off = pix + (unsigned)(8 * min(g2, max((a.C - 32 * ks - 8) / 8, 0)) * plane);
@@ -288,11 +294,13 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             const int b = item / a.tiles, tile = item - b * a.tiles;
             const int ty0 = (tile / a.tiles_x) * FB_TH, tx0 = (tile % a.tiles_x) * FB_TW;
             const float* V = a.V + (long)b * a.v_bs;
+            const long plane = a.v_tm ? 256 : (long)a.H * a.W;          // (channel stride of v)
 #pragma unroll
             for (int j = 0; j < (APPLY ? 3 : 0); ++j) {
                 const int p = 16 * (wave + 8 * j) + r2, ph = p / FB_HC, pc = p - ph * FB_HC;
-                const int gy = ty0 - 1 + ph, gx = tx0 - 1 + pc;
-                const unsigned pix = (unsigned)(min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1));
+                const int gy = min(max(ty0 - 1 + ph, 0), a.H - 1), gx = min(max(tx0 - 1 + pc, 0), a.W - 1);
+                const unsigned pix = a.v_tm ? (unsigned)(((gy >> 3) * a.tiles_x + (gx >> 5)) * (a.C * 256) + (gy & 7) * FB_TW + (gx & 31))
+                                            : (unsigned)(gy * a.W + gx);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const unsigned off = pix + (unsigned)(8 * min(g2, max((a.C - 32 * ks - 8) / 8, 0)) * plane);
@@ -608,6 +616,20 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                         for (int q = 0; q < 2; ++q) yt[tvoff + (16 * hf + e) * 256 + q * FB_TW] = oprev[hf][q][e];
                 return;
             }
+            if (a.v_tm && 32 * st >= 2 * a.C) {
+                // v tile-major inside the v part of Y (channels [2C, 3C): C N floats per image, blocks of C x 256)
+                float* yt = Y + 2L * a.C * plane + (long)tile * (a.C * 256L) + (long)(32 * st - 2 * a.C) * 256;
+                const unsigned tvoff = (unsigned)(4 * g * 256 + (2 * (wave >> 1)) * FB_TW + 16 * (wave & 1) + (t4 & 15));
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (32 * st + 16 * hf + 4 * g + e < a.M) {
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) yt[tvoff + (16 * hf + e) * 256 + q * FB_TW] = oprev[hf][q][e];
+                        }
+                return;
+            }
             const unsigned svoff = (unsigned)((4 * g) * plane + (long)sy * a.W + sx);
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
@@ -785,7 +807,11 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                     if (oy0 + q >= a.H) continue;
                     const float4 v = make_float4(acc2[q][c][0] * a.inv_s2, acc2[q][c][1] * a.inv_s2,
                                                  acc2[q][c][2] * a.inv_s2, acc2[q][c][3] * a.inv_s2);
-                    *reinterpret_cast<float4*>(Y + (long)co * plane + (long)(oy0 + q) * a.W + ox) = v;
+                    if (a.y_tm)
+                        *reinterpret_cast<float4*>(Y + (long)tile * (a.C * 256L) + co * 256 + (2 * (wave >> 1) + q) * FB_TW +
+                                                   16 * (wave & 1) + 4 * ((t3 & 63) >> 4)) = v;
+                    else
+                        *reinterpret_cast<float4*>(Y + (long)co * plane + (long)(oy0 + q) * a.W + ox) = v;
                 }
             }
         }
@@ -841,7 +867,7 @@ extern "C" int irm_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const
     FusedArgs a;
     a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.rec = rec; a.w2 = w2; a.bias2 = bias2;
     a.C = C; a.H = H; a.W = W; a.S = (hid + 15) / 16; a.M = 0; a.ln_mode = ln_mode; a.eps = eps; a.inv_s1 = inv_s1; a.inv_s2 = inv_s2;
-    a.V = nullptr; a.v_bs = 0; a.mf = nullptr; a.mf_bs = 0; a.bias_o = nullptr; a.tm = 0;
+    a.V = nullptr; a.v_bs = 0; a.mf = nullptr; a.mf_bs = 0; a.bias_o = nullptr; a.tm = 0; a.x_tm = 0; a.v_tm = 0; a.y_tm = 0;
 #ifdef FB_STAMP
     a.dbg = getenv("FB_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FB_DBG_PTR"), nullptr, 0) : nullptr;
 #endif
@@ -862,7 +888,8 @@ extern "C" int irm_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const
 extern "C" int irm_attn_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const float* bias2, const float* x, long x_bs,
                                              const float* v, long v_bs, const float* mfold_frag, const float* bias_o,
                                              float* y, long y_bs, int ln_mode, float eps, float inv_s1, float inv_s2, int B,
-                                             int C, int hid, int H, int W, hipStream_t stream) {
+                                             int C, int hid, int H, int W, int lay, hipStream_t stream) {
+    if (lay < 0 || lay > 7 || (lay && ((H & 7) || (W & 31)))) return IRM_EINVAL;
     if (!rec || !w2 || !x || !v || !mfold_frag || !y || x == y || v == y || B <= 0 || C <= 0 || hid <= 0 || H <= 0 || W <= 0)
         return IRM_EINVAL;
     if (C > 96 || (C & 15) || (W & 3)) return IRM_EINVAL;
@@ -874,7 +901,7 @@ extern "C" int irm_attn_gdfn_fused_f16x3_f32(const float* rec, const float* w2, 
     a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.rec = rec; a.w2 = w2; a.bias2 = bias2;
     a.C = C; a.H = H; a.W = W; a.S = (hid + 15) / 16; a.M = 0; a.ln_mode = ln_mode; a.eps = eps; a.inv_s1 = inv_s1; a.inv_s2 = inv_s2;
     const int ks = (C + 31) / 32, ct = (C + 15) / 16;
-    a.V = v; a.v_bs = v_bs; a.mf = mfold_frag; a.mf_bs = (long)2 * ks * ks * 512; a.bias_o = bias_o; a.tm = 0;
+    a.V = v; a.v_bs = v_bs; a.mf = mfold_frag; a.mf_bs = (long)2 * ks * ks * 512; a.bias_o = bias_o; a.tm = 0; a.x_tm = lay & 1; a.v_tm = (lay >> 1) & 1; a.y_tm = (lay >> 2) & 1;
 #ifdef FB_STAMP
     a.dbg = getenv("FB_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FB_DBG_PTR"), nullptr, 0) : nullptr;
 #endif
@@ -894,7 +921,7 @@ static int qkv_dw_fused(const float* rec, const float* x, long x_bs, float* y, l
     FusedArgs a;
     a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.rec = rec; a.w2 = nullptr; a.bias2 = nullptr;
     a.C = C; a.H = H; a.W = W; a.S = (M + 31) / 32; a.M = M; a.ln_mode = ln_mode; a.eps = eps; a.inv_s1 = inv_s1; a.inv_s2 = 0.f;
-    a.V = nullptr; a.v_bs = 0; a.mf = nullptr; a.mf_bs = 0; a.bias_o = nullptr; a.tm = tm;
+    a.V = nullptr; a.v_bs = 0; a.mf = nullptr; a.mf_bs = 0; a.bias_o = nullptr; a.tm = tm & 1; a.x_tm = (tm >> 1) & 1; a.v_tm = (tm >> 2) & 1; a.y_tm = 0;
 #ifdef FB_STAMP
     a.dbg = getenv("FB_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FB_DBG_PTR"), nullptr, 0) : nullptr;
 #endif
@@ -914,7 +941,8 @@ extern "C" int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long
 
 // q, k (output channels [0, 2C)) tile-major inside y's q, k part, v planar as before (header).
 extern "C" int irm_qkv_dw_fused_tm_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode,
-                                             float eps, float inv_s1, int B, int C, int H, int W, hipStream_t stream) {
+                                             float eps, float inv_s1, int B, int C, int H, int W, int x_tm, int v_tm,
+                                             hipStream_t stream) {
     if (C <= 0 || (C & 15) || H <= 0 || W <= 0 || (H & 7) || (W & 31)) return IRM_EINVAL;
-    return qkv_dw_fused(rec, x, x_bs, y, y_bs, ln_mode, eps, inv_s1, B, C, 3 * C, H, W, 1, stream);
+    return qkv_dw_fused(rec, x, x_bs, y, y_bs, ln_mode, eps, inv_s1, B, C, 3 * C, H, W, 1 | (x_tm ? 2 : 0) | (v_tm ? 4 : 0), stream);
 }

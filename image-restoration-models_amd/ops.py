@@ -291,9 +291,11 @@ def mfold_frag_numel(C: int) -> int:
     return 2 * ks * ks * 512
 
 
-def attn_gdfn_fused(pk, x, v, mfold_frag, y, C: int, hid: int, *, ln_mode, bias_o=None, bias=None, eps: float = 1e-5):
+def attn_gdfn_fused(pk, x, v, mfold_frag, y, C: int, hid: int, *, ln_mode, bias_o=None, bias=None, eps: float = 1e-5,
+                    x_tm: bool = False, v_tm: bool = False, y_tm: bool = False):
     """y = x' + GDFN(x'), x' = x + bias_o + Mfold[b] v in one kernel (restormer.py:131, 147-148; y is neither x nor v);
-    pk = _hip.pack_gdfn_fused(..., kperm=True), mfold_frag from mdta_fold(..., frag=True)."""
+    pk = _hip.pack_gdfn_fused(..., kperm=True), mfold_frag from mdta_fold(..., frag=True).
+    x_tm / v_tm / y_tm: that tensor in the tile-major layout of include/irm_hip.h (whole 8 x 32 tiles)."""
     _chk(x, "x"), _chk(y, "y"), _chk(v, "v")
     B, _, H, W = x.shape
     assert x.data_ptr() != y.data_ptr() and x.shape[1] >= C and y.shape[1] >= C and v.shape[1] >= C and C % 16 == 0
@@ -304,7 +306,7 @@ def attn_gdfn_fused(pk, x, v, mfold_frag, y, C: int, hid: int, *, ln_mode, bias_
     _launch("attn_gdfn_fused", flops, 4.0 * B * N * 3 * C, "irm_attn_gdfn_fused_f16x3_f32", _hip.ptr(rec), _hip.ptr(w2),
             _hip.ptr(bias), _hip.ptr(x), _bs(x), _hip.ptr(v), _bs(v), _hip.ptr(mfold_frag), _hip.ptr(bias_o),
             _hip.ptr(y), _bs(y), int(ln_mode), float(eps), float(inv_s1), float(inv_s2), B, C, hid, H, W,
-            tag=f"C{C} hid{hid} {H}x{W} B{B}")
+            int(x_tm) | 2 * int(v_tm) | 4 * int(y_tm), tag=f"C{C} hid{hid} {H}x{W} B{B}")
 
 
 def can_qk_tile_major(C: int, heads: int, H: int, W: int) -> bool:
@@ -312,7 +314,8 @@ def can_qk_tile_major(C: int, heads: int, H: int, W: int) -> bool:
     return C % 16 == 0 and C % heads == 0 and C // heads in (48, 96) and H % 8 == 0 and W % 32 == 0
 
 
-def qkv_dw_fused(pk, x, y, C: int, M: int, *, ln_mode, eps: float = 1e-5, tm: bool = False):
+def qkv_dw_fused(pk, x, y, C: int, M: int, *, ln_mode, eps: float = 1e-5, tm: bool = False, x_tm: bool = False,
+                 v_tm: bool = False):
     """y[:, :M] = dw3x3(W @ LN(x) + b) in one kernel (y is not x); pk = _hip.pack_qkv_fused(...).
     tm (M = 3C): q, k tile-major inside y[:, :2C] (include/irm_hip.h), for mdta_fold(tm=True) only."""
     _chk(x, "x"), _chk(y, "y")
@@ -324,8 +327,9 @@ def qkv_dw_fused(pk, x, y, C: int, M: int, *, ln_mode, eps: float = 1e-5, tm: bo
         assert M == 3 * C and y.shape[1] == M and H % 8 == 0 and W % 32 == 0
         _launch("qkv_dw_fused", B * N * (2.0 * M * C + 18.0 * M), 4.0 * B * N * (C + M), "irm_qkv_dw_fused_tm_f16x3_f32",
                 _hip.ptr(rec), _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y), int(ln_mode), float(eps), float(inv_s1), B, C,
-                H, W, tag=f"C{C} M{M} {H}x{W} B{B} tm")
+                H, W, int(x_tm), int(v_tm), tag=f"C{C} M{M} {H}x{W} B{B} tm")
         return
+    assert not (x_tm or v_tm), "tile-major x / v need tm=True"
     _launch("qkv_dw_fused", B * N * (2.0 * M * C + 18.0 * M), 4.0 * B * N * (C + M), "irm_qkv_dw_fused_f16x3_f32",
             _hip.ptr(rec), _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y), int(ln_mode), float(eps), float(inv_s1), B, C, M,
             H, W, tag=f"C{C} M{M} {H}x{W} B{B}")

@@ -351,7 +351,8 @@ class Restormer(nn.Module):
                         stats_out=stats if emit else None, split=s_pout)
         return emit
 
-    def _block_fused(self, blk: TransformerBlock, w: dict, x: torch.Tensor, alt: torch.Tensor) -> torch.Tensor:
+    def _block_fused(self, blk: TransformerBlock, w: dict, x: torch.Tensor, alt: torch.Tensor, x_tm: bool = False,
+                     y_tm: bool = False) -> torch.Tensor:
         """One TransformerBlock on the whole-branch kernels (C <= 96): x -> alt, returns alt.
 
         qkv_dw_fused (LN1 + qkv + depth-wise, restormer.py:105-106) -> Gram + softmax + fold (:118-129) ->
@@ -365,7 +366,10 @@ class Restormer(nn.Module):
         # q, k tile-major for the Gram pass (its only reader) where the f16x3 ring pass runs on whole tiles
         tm = ("gram_s" in w and ops.can_qk_tile_major(C, heads, H, W) and not os.environ.get("IRM_GRAM_EXACT")
               and not os.environ.get("IRM_NO_QK_TM"))
-        ops.qkv_dw_fused(w["qkv_f"], x, qkv, C, 3 * C, ln_mode=blk.norm1.mode, tm=tm)
+        fa = "gdfn_fa" in w and not os.environ.get("IRM_NO_APPLY_FUSE")
+        assert not (x_tm or y_tm) or (tm and fa), "tile-major x / y: only between the kernels that understand them"
+        v_tm = tm and fa and not os.environ.get("IRM_NO_ACT_TM")
+        ops.qkv_dw_fused(w["qkv_f"], x, qkv, C, 3 * C, ln_mode=blk.norm1.mode, tm=tm, x_tm=x_tm, v_tm=v_tm)
         _, nchunk, rec = ops.mdta_plan(B, C, heads, N)
         part = self._buf("gram_part", B * heads * nchunk * rec, dev)
         gsum = self._buf("gram_sum", B * heads * rec, dev)
@@ -376,7 +380,7 @@ class Restormer(nn.Module):
             mfold = torch.zeros(B * mfold_n, dtype=torch.float32, device=dev)
             ws[("mfold", C, B)] = mfold
         s_fold = w.get("mfold_split", False)
-        if "gdfn_fa" in w and not os.environ.get("IRM_NO_APPLY_FUSE"):
+        if fa:
             # x' = x + project_out(attn @ v) is formed in the GDFN kernel's prologue and never written (:131, 147-148)
             mfrag = ws.get(("mfold_frag", C, B))
             if mfrag is None or mfrag.device != dev:
@@ -384,7 +388,7 @@ class Restormer(nn.Module):
                 ws[("mfold_frag", C, B)] = mfrag
             ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfrag, C, heads, gram_scale=w.get("gram_s"), frag=True, tm=tm)
             ops.attn_gdfn_fused(w["gdfn_fa"], x, qkv[:, 2 * C:], mfrag, alt, C, hid, ln_mode=blk.norm2.mode,
-                                bias_o=w["wout_b"], bias=w["pout_b"])
+                                bias_o=w["wout_b"], bias=w["pout_b"], x_tm=x_tm, v_tm=v_tm, y_tm=y_tm)
             return alt
         ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=s_fold, gram_scale=w.get("gram_s"), tm=tm)
         ops.gemm1x1(mfold, qkv[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n, split=s_fold)
@@ -397,8 +401,16 @@ class Restormer(nn.Module):
         if (len(blocks) and "gdfn_f" in pk[f"{name}.0"] and ops.can_fuse_gdfn(C, W) and (H * W) % 4 == 0
                 and not os.environ.get("IRM_NO_FUSE_BLOCK")):
             cur, alt = x, self._buf(f"alt_{C}", B * C * H * W, x.device).view(B, C, H, W)
+            # between the blocks of a stage x travels tile-major (include/irm_hip.h): the first block reads the planar
+            # stage input, the last one writes the planar stage output
+            heads = blocks[0].attn.num_heads
+            act_tm = (all("gdfn_fa" in pk[f"{name}.{i}"] and "gram_s" in pk[f"{name}.{i}"] for i in range(len(blocks)))
+                      and ops.can_qk_tile_major(C, heads, H, W) and not os.environ.get("IRM_NO_APPLY_FUSE")
+                      and not os.environ.get("IRM_GRAM_EXACT") and not os.environ.get("IRM_NO_QK_TM")
+                      and not os.environ.get("IRM_NO_ACT_TM"))
             for i, blk in enumerate(blocks):
-                out = self._block_fused(blk, pk[f"{name}.{i}"], cur, alt)
+                out = self._block_fused(blk, pk[f"{name}.{i}"], cur, alt, x_tm=act_tm and i > 0,
+                                        y_tm=act_tm and i + 1 < len(blocks))
                 cur, alt = out, cur
             if cur is not x:                           # odd number of blocks: the stage result belongs in x
                 x.copy_(cur)

@@ -207,9 +207,14 @@ int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long x_bs, floa
  * of y - [H/8 * W/32 tiles][2C][256 pixels of the 8 x 32 tile, row-major] per image, the same 2C N floats - and v planar
  * at channels [2C, 3C) as before.  q, k are read by the Gram pass only (irm_mdta_gram_tm_f16x3_f32): a stage of that pass
  * then reads 2c row segments 1 KiB apart inside one contiguous block instead of 2c segments a plane apart.
- * H % 8 == 0, W % 32 == 0, C % 16 == 0. */
+ * H % 8 == 0, W % 32 == 0, C % 16 == 0.
+ * Tile-major activations inside a stage (x_tm / v_tm / the `lay` bits of irm_attn_gdfn_fused_f16x3_f32): element
+ * (channel, y, x) of an image's Cb-channel tensor at ((y >> 3) (W / 32) + (x >> 5)) Cb 256 + channel 256 + (y & 7) 32 + (x & 31):
+ * an 8 x 32 tile's pixels of all channels form ONE contiguous block, so the stores of a work item and the reads of its
+ * interior stay inside one block (the planar layout spreads them over Cb planes).  x_tm: x is read in that layout (Cb = C);
+ * v_tm: v is written in it inside channels [2C, 3C) of y (Cb = C).  The first kernel of a stage reads planar, the last writes planar. */
 int irm_qkv_dw_fused_tm_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode, float eps,
-                                  float inv_s1, int B, int C, int H, int W, irm_stream_t stream);
+                                  float inv_s1, int B, int C, int H, int W, int x_tm, int v_tm, irm_stream_t stream);
 /* irm_attn_gdfn_fused_f16x3_f32 (round 3): the last step of the attention branch inside the GDFN kernel's prologue,
  *   x' = x + bias_o + Mfold[b] v          (restormer.py:131, 147: project_out(attn @ v) + x, Mfold by irm_mdta_finalize_frag_f16x3_f32)
  *   y  = x' + project_out(gelu_erf(dw(h)[:hid]) * dw(h)[hid:]) + bias2,  h = project_in(LN(x')) + b      (:76-93, 148)
@@ -218,11 +223,12 @@ int irm_qkv_dw_fused_tm_f16x3_f32(const float* rec, const float* x, long x_bs, f
  * mfold_frag: [B][2 KS][KS][hi|lo][64 lanes][8 halves], KS = ceil(C/32); bias_o: [C] or NULL; C % 16 == 0.
  * rec as for irm_gdfn_fused_f16x3_f32 except for the order of project_in's input channels: half j of lane 16 g + m of
  * k-step ks <-> input channel 16 (2 ks + (j >> 2)) + 4 g + (j & 3) (the order in which the MFMA of the first step
- * leaves x' in the registers; Python: _hip.pack_gdfn_fused(..., kperm=True)). */
+ * leaves x' in the registers; Python: _hip.pack_gdfn_fused(..., kperm=True)).
+ * lay: bit 0 - x tile-major, bit 1 - v tile-major, bit 2 - y written tile-major (above; needs H % 8 == 0, W % 32 == 0). */
 int irm_attn_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const float* bias2, const float* x, long x_bs,
                                   const float* v, long v_bs, const float* mfold_frag, const float* bias_o, float* y,
                                   long y_bs, int ln_mode, float eps, float inv_s1, float inv_s2, int B, int C, int hid,
-                                  int H, int W, irm_stream_t stream);
+                                  int H, int W, int lay, irm_stream_t stream);
 
 /* MDTA pass 1: per-chunk partial Gram matrices and squared norms.
  * qkv: [B][3C][N] (after qkv_dwconv; q rows [0,C), k rows [C,2C)).

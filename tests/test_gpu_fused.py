@@ -129,6 +129,45 @@ def test_attn_gdfn_fused(dev, C, hid, H, W, B, ln, bias):
     assert torch.equal(y2.cpu(), y[:, 2:2 + C]), "not deterministic"
 
 
+def to_tm(t):
+    """[B][C][H][W] planar -> the same container holding the tile-major order of include/irm_hip.h ([tile][C][8 x 32])."""
+    B, C, H, W = t.shape
+    return t.reshape(B, C, H // 8, 8, W // 32, 32).permute(0, 2, 4, 1, 3, 5).reshape(B, C, H, W).contiguous()
+
+
+def from_tm(t):
+    B, C, H, W = t.shape
+    return t.reshape(B, H // 8, W // 32, C, 8, 32).permute(0, 3, 1, 4, 2, 5).reshape(B, C, H, W).contiguous()
+
+
+@pytest.mark.parametrize("C,hid,H,W,B,lay", [(96, 255, 16, 64, 2, 7), (96, 255, 24, 32, 1, 1), (48, 127, 8, 96, 3, 2),
+                                             (96, 255, 40, 64, 1, 4), (48, 127, 16, 32, 2, 5), (64, 170, 8, 64, 1, 3)])
+def test_attn_gdfn_fused_tile_major_layouts(dev, C, hid, H, W, B, lay):
+    """Every combination of tile-major x (bit 0) / v (bit 1) / y (bit 2) gives the bytes of the planar call."""
+    tag = f"al{C}_{H}_{W}_{lay}"
+    big = rnd(tag + "x", (B, C + 3, H, W), -1.5, 2.0)
+    vbig = rnd(tag + "v", (B, 3 * C, H, W), -2.0, 2.0)
+    mf = rnd(tag + "m", (B, C, C), -0.2, 0.2)
+    lnw, lnb = rnd(tag + "lw", (C,), 0.5, 1.5), rnd(tag + "lb", (C,), -0.2, 0.2)
+    pk = _hip.pack_gdfn_fused(rnd(tag + "pi", (2 * hid, C), -.3, .3).to(dev), None, rnd(tag + "dw", (2 * hid, 9), -.4, .4),
+                              None, rnd(tag + "po", (C, hid), -.3, .3), lnw, lnb, kperm=True)
+    frag = _hip.pack_mfold_frag(mf).to(dev)
+    bo = rnd(tag + "bo", (C,), -0.3, 0.3).to(dev)
+    y0 = torch.empty(B, C, H, W, device=dev)
+    ops.attn_gdfn_fused(pk, big.to(dev)[:, 1:1 + C], vbig.to(dev)[:, 2 * C:], frag, y0, C, hid, ln_mode=1, bias_o=bo)
+    xt, vt = big.clone(), vbig.clone()
+    if lay & 1:
+        xt[:, 1:1 + C] = to_tm(big[:, 1:1 + C])
+    if lay & 2:
+        vt[:, 2 * C:] = to_tm(vbig[:, 2 * C:])
+    yb = torch.full((B, C + 2, H, W), 7.0, device=dev)
+    ops.attn_gdfn_fused(pk, xt.to(dev)[:, 1:1 + C], vt.to(dev)[:, 2 * C:], frag, yb[:, 2:2 + C], C, hid, ln_mode=1, bias_o=bo,
+                        x_tm=bool(lay & 1), v_tm=bool(lay & 2), y_tm=bool(lay & 4))
+    y = yb[:, 2:2 + C].cpu()
+    assert torch.equal(from_tm(y) if lay & 4 else y, y0.cpu())
+    assert torch.all(yb[:, :2] == 7.0)
+
+
 def test_gdfn_fused_deterministic(dev):
     C, hid, H, W = 96, 255, 32, 64
     x = rnd("detx", (2, C, H, W), -2, 2).to(dev)
@@ -202,8 +241,13 @@ def test_qk_tile_major_chain(dev, C, heads, H, W, B):
     gs = _hip.gram_scales(w.view(M, C, 1, 1), None, dw_w.view(M, 1, 3, 3), None, lnw, lnb, True).to(dev)
     temp, wout = rnd(tag + "t", (heads,), 2.0, 6.0).to(dev), rnd(tag + "wo", (C, C), -0.3, 0.3).to(dev)
     res = []
-    for tm in (False, True):
+    for tm in (False, True, 2):
         qkv = torch.full((B, M, H, W), 7.0, device=dev)
+        if tm == 2:        # x read tile-major, v written tile-major as well
+            ops.qkv_dw_fused(pk, to_tm(x.cpu()).to(dev), qkv, C, M, ln_mode=1, tm=True, x_tm=True, v_tm=True)
+            v_back = from_tm(qkv[:, 2 * C:].cpu())
+            assert torch.equal(v_back, res[0][0][:, 2 * C:]) and torch.equal(qkv[:, :2 * C].cpu(), res[1][0][:, :2 * C])
+            continue
         ops.qkv_dw_fused(pk, x, qkv, C, M, ln_mode=1, tm=tm)
         _, nchunk, rec = ops.mdta_plan(B, C, heads, N)
         part = torch.full((B * heads * nchunk * rec,), float("nan"), device=dev)
