@@ -56,10 +56,12 @@ struct FusedArgs {
     const float* mf; long mf_bs;          // [B][CT][KS][hi|lo][64 lanes][8 halves] folded per-image matrix (mdta_finalize, fragment order)
     const float* bias_o;                  // [C] attention project_out bias or null
     int tm;                               // !GATE: q, k (channels < 2C) stored tile-major [tile][2C][256] inside Y's q, k part
-    // Tile-major activations between the kernels of a stage (whole 8 x 32 tiles): element (channel, y, x) of an image at
-    // ((y >> 3) tiles_x + (x >> 5)) (Cb 256) + channel 256 + (y & 7) 32 + (x & 31), Cb = channels of that tensor - a tile's
-    // pixels of all channels are ONE contiguous block (the stores of an item, and the reads of its interior, stay inside it).
-    int x_tm, v_tm, y_tm;                 // X; V (APPLY input / !GATE output channels >= 2C); Y (GATE output)
+    // Tile-major, channel-LAST activations between the kernels of a stage (whole 8 x 32 tiles): element (channel, y, x) of an
+    // image at (((y >> 3) tiles_x + (x >> 5)) 256 + (y & 7) 32 + (x & 31)) Cb + channel, Cb = channels of that tensor.  A pixel's
+    // channels are contiguous: lane (pixel, g) fetches its 8 channels of a k-step as two 16-byte loads (planar: eight 4-byte
+    // loads from eight planes), every fetched 128-byte line is used whole (planar: the 34-pixel halo rows start one pixel
+    // before a line boundary - ~1.9x the bytes), and a tile's stores stay inside one contiguous Cb KiB block.
+    int x_tm, v_tm, y_tm;                 // X; V (APPLY input / !GATE output channels >= 2C); Y (GATE && YCL output)
 #ifdef FB_STAMP
     unsigned long long* dbg;
 #endif
@@ -183,9 +185,13 @@ __device__ __forceinline__ void fb_dma(const float* src, float* dst, int wave, i
 // (x + bias_o) / 16.  The MFMA leaves lane (r, g) with channels 16 t + 4 g + e of pixel r, so in this variant x is
 // loaded in that order: k-slot (ks, g, e) of project_in <-> channel 16 (2 ks + (e >> 2)) + 4 g + (e & 3) (the host
 // packs project_in's columns accordingly; LayerNorm does not care about the order).  C % 16 == 0.
-template <int KS, int CT, bool GATE, bool APPLY = false>
+// YCL (APPLY only): y is written in the tile-major channel-last layout (FusedArgs).  project_out then runs with its
+// operands swapped (weights = A: the MFMA leaves lane (pixel, g) with channels 16 c + 4 g + e - 16-byte stores), and the
+// residual x' reaches the accumulators through a pixel-major LDS image instead of the transposed one.
+template <int KS, int CT, bool GATE, bool APPLY = false, bool YCL = false>
 __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
     static_assert(!APPLY || GATE, "APPLY is a variant of the GDFN kernel");
+    static_assert(!YCL || APPLY, "YCL is a variant of the APPLY kernel");
     IRM_KERNEL_ENTRY();
     constexpr int W1F = KS * 1024;                 // floats of project_in weights per record (2 tiles x KS x hi/lo x 1 KiB)
     constexpr int RECF = W1F + 512;                // + depth-wise taps [10][32], bias [32], pad
@@ -259,13 +265,36 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             const int b = item / a.tiles, tile = item - b * a.tiles;
             const int ty0 = (tile / a.tiles_x) * FB_TH, tx0 = (tile % a.tiles_x) * FB_TW;
             const float* X = a.X + (long)b * a.x_bs;
-            const long plane = a.x_tm ? 256 : (long)a.H * a.W;          // (channel stride of x)
+            const long plane = (long)a.H * a.W;
+            if (a.x_tm) {                                  // tile-major, channel-last: two 16-byte loads per k-step
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int p = 16 * (wave + 8 * j) + r2, ph = p / FB_HC, pc = p - ph * FB_HC;
+                    const int gy = min(max(ty0 - 1 + ph, 0), a.H - 1), gx = min(max(tx0 - 1 + pc, 0), a.W - 1);
+                    const float* xp = X + (unsigned)((((gy >> 3) * a.tiles_x + (gx >> 5)) * 256 + (gy & 7) * FB_TW + (gx & 31)) * a.C);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        int c0, c1;
+                        if constexpr (APPLY) {
+                            const int tmax = a.C / 16 - 1;
+                            c0 = 16 * min(2 * ks, tmax) + 4 * g2;
+                            c1 = 16 * min(2 * ks + 1, tmax) + 4 * g2;
+                        } else {
+                            c0 = 32 * ks + 8 * min(g2, max((a.C - 32 * ks - 8) / 8, 0));
+                            c1 = c0 + 4;
+                        }
+                        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(xp + c0), hi4 = *reinterpret_cast<const f32x4*>(xp + c1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { xr[j][ks][e] = lo4[e]; xr[j][ks][4 + e] = hi4[e]; }
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int p = 16 * (wave + 8 * j) + r2, ph = p / FB_HC, pc = p - ph * FB_HC;
                 const int gy = min(max(ty0 - 1 + ph, 0), a.H - 1), gx = min(max(tx0 - 1 + pc, 0), a.W - 1);
-                const unsigned pix = a.x_tm ? (unsigned)(((gy >> 3) * a.tiles_x + (gx >> 5)) * (a.C * 256) + (gy & 7) * FB_TW + (gx & 31))
-                                            : (unsigned)(gy * a.W + gx);
+                const unsigned pix = (unsigned)(gy * a.W + gx);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const unsigned off = pix + (unsigned)(8 * min(g2, max((a.C - 32 * ks - 8) / 8, 0)) * plane);
@@ -294,13 +323,28 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             const int b = item / a.tiles, tile = item - b * a.tiles;
             const int ty0 = (tile / a.tiles_x) * FB_TH, tx0 = (tile % a.tiles_x) * FB_TW;
             const float* V = a.V + (long)b * a.v_bs;
-            const long plane = a.v_tm ? 256 : (long)a.H * a.W;          // (channel stride of v)
+            const long plane = (long)a.H * a.W;
+            if (a.v_tm) {
+#pragma unroll
+                for (int j = 0; j < (APPLY ? 3 : 0); ++j) {
+                    const int p = 16 * (wave + 8 * j) + r2, ph = p / FB_HC, pc = p - ph * FB_HC;
+                    const int gy = min(max(ty0 - 1 + ph, 0), a.H - 1), gx = min(max(tx0 - 1 + pc, 0), a.W - 1);
+                    const float* vp = V + (unsigned)((((gy >> 3) * a.tiles_x + (gx >> 5)) * 256 + (gy & 7) * FB_TW + (gx & 31)) * a.C);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const int c0 = 32 * ks + 8 * min(g2, max((a.C - 32 * ks - 8) / 8, 0));
+                        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(vp + c0), hi4 = *reinterpret_cast<const f32x4*>(vp + c0 + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { vr[j][ks][e] = lo4[e]; vr[j][ks][4 + e] = hi4[e]; }
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < (APPLY ? 3 : 0); ++j) {
                 const int p = 16 * (wave + 8 * j) + r2, ph = p / FB_HC, pc = p - ph * FB_HC;
                 const int gy = min(max(ty0 - 1 + ph, 0), a.H - 1), gx = min(max(tx0 - 1 + pc, 0), a.W - 1);
-                const unsigned pix = a.v_tm ? (unsigned)(((gy >> 3) * a.tiles_x + (gx >> 5)) * (a.C * 256) + (gy & 7) * FB_TW + (gx & 31))
-                                            : (unsigned)(gy * a.W + gx);
+                const unsigned pix = (unsigned)(gy * a.W + gx);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const unsigned off = pix + (unsigned)(8 * min(g2, max((a.C - 32 * ks - 8) / 8, 0)) * plane);
@@ -396,7 +440,27 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             __builtin_amdgcn_s_barrier();
             FB_T(9);
         }
-        if constexpr (GATE) {
+        constexpr int RP = 32 * KS + 4;                // YCL: floats per pixel of the residual image (16-byte aligned; the 16
+        static_assert(!YCL || 256 * RP * 4 <= 2 * PL_B, "residual image");        // pixels of a lane group on 16 bank quads)
+        if constexpr (YCL) {
+            // x' of the 256 interior pixels pixel-major [pixel][channel] into the free image area: the swapped project_out
+            // wants the residual as (pixel on the lane, channels 16 c + 4 g + e) - the order the registers already have,
+            // but for the pixels of the lane's STENCIL position
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int ip = (hr[j] - 1) * FB_TW + hc[j] - 1;
+                if (pv[j] && hr[j] >= 1 && hr[j] <= FB_TH && hc[j] >= 1 && hc[j] <= FB_TW) {
+                    const unsigned vt = (unsigned)(PL_OFF + (ip * RP + 4 * g) * 4);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        if (32 * ks < a.C)
+                            fb_st<f32x4>(lds, vt, 32 * ks * 4, (f32x4){xr[j][ks][0], xr[j][ks][1], xr[j][ks][2], xr[j][ks][3]});
+                        if (32 * ks + 16 < a.C)
+                            fb_st<f32x4>(lds, vt, (32 * ks + 16) * 4, (f32x4){xr[j][ks][4], xr[j][ks][5], xr[j][ks][6], xr[j][ks][7]});
+                    }
+                }
+            }
+        } else if constexpr (GATE) {
             // The residual is the tile's own input, already in registers (xr: pixel on the lane, channels in the
             // registers); project_out's accumulators want it transposed (channel on the lane, 4 pixels in the registers).
             // The image area is still free: park the 256 interior pixels channel-major there (row stride RT floats = 66
@@ -495,6 +559,20 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const float rsc = 1.0f / a.inv_s2;
+            if constexpr (YCL) {
+                const unsigned vt = (unsigned)(PL_OFF + (((2 * (wave >> 1)) * FB_TW + 16 * (wave & 1) + r) * RP + 4 * g) * 4);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (a.bias2 && 16 * c < a.C) bv = *reinterpret_cast<const f32x4*>(a.bias2 + 16 * c + 4 * g);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+                        if (16 * c < a.C) rr = fb_ld<f32x4>(lds, vt, (q * FB_TW * RP + 16 * c) * 4);
+                        acc2[q][c] = (f32x4){(rr[0] + bv[0]) * rsc, (rr[1] + bv[1]) * rsc, (rr[2] + bv[2]) * rsc, (rr[3] + bv[3]) * rsc};
+                    }
+                }
+            } else {
             const unsigned vt = (unsigned)(PL_OFF + (r * RT + 64 * (wave >> 1) + 16 * (wave & 1) + 4 * g) * 4);
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
@@ -506,6 +584,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                     const f32x4 rr = fb_ld<f32x4>(lds, vtc, q * FB_TW * 4);
                     acc2[q][c] = (f32x4){(rr[0] + bv) * rsc, (rr[1] + bv) * rsc, (rr[2] + bv) * rsc, (rr[3] + bv) * rsc};
                 }
+            }
             }
             fb_st<f32x4>(lds, vpark, 0, acc2[1][CT - 1]);
         }
@@ -617,17 +696,18 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                 return;
             }
             if (a.v_tm && 32 * st >= 2 * a.C) {
-                // v tile-major inside the v part of Y (channels [2C, 3C): C N floats per image, blocks of C x 256)
-                float* yt = Y + 2L * a.C * plane + (long)tile * (a.C * 256L) + (long)(32 * st - 2 * a.C) * 256;
-                const unsigned tvoff = (unsigned)(4 * g * 256 + (2 * (wave >> 1)) * FB_TW + 16 * (wave & 1) + (t4 & 15));
+                // v tile-major channel-last inside the v part of Y (channels [2C, 3C): C N floats per image): the lane's 4
+                // channels of a pixel are one 16-byte store
+                float* yt = Y + 2L * a.C * plane + (long)tile * (a.C * 256L) + (32 * st - 2 * a.C) + 4 * g;
+                const unsigned px = (unsigned)((2 * (wave >> 1)) * FB_TW + 16 * (wave & 1) + (t4 & 15));
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf)
+                    if (32 * st + 16 * hf + 4 * g + 3 < a.M) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (32 * st + 16 * hf + 4 * g + e < a.M) {
-#pragma unroll
-                            for (int q = 0; q < 2; ++q) yt[tvoff + (16 * hf + e) * 256 + q * FB_TW] = oprev[hf][q][e];
-                        }
+                        for (int q = 0; q < 2; ++q)
+                            *reinterpret_cast<f32x4*>(yt + (px + q * FB_TW) * a.C + 16 * hf) =
+                                (f32x4){oprev[hf][q][0], oprev[hf][q][1], oprev[hf][q][2], oprev[hf][q][3]};
+                    }
                 return;
             }
             const unsigned svoff = (unsigned)((4 * g) * plane + (long)sy * a.W + sx);
@@ -763,9 +843,15 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         f32x4& t = (q == 1 && c == CT - 1) ? accp : acc2[q][c];
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(fb_h8, Gl[q]), bh, t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(fb_h8, Gh[q]), bl, t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(fb_h8, Gh[q]), bh, t, 0, 0, 0);
+                        if constexpr (YCL) {        // weights as the A operand: the lane receives 4 channels of its pixel
+                            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, __builtin_bit_cast(fb_h8, Gl[q]), t, 0, 0, 0);
+                            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, __builtin_bit_cast(fb_h8, Gh[q]), t, 0, 0, 0);
+                            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, __builtin_bit_cast(fb_h8, Gh[q]), t, 0, 0, 0);
+                        } else {
+                            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(fb_h8, Gl[q]), bh, t, 0, 0, 0);
+                            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(fb_h8, Gh[q]), bl, t, 0, 0, 0);
+                            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(fb_h8, Gh[q]), bh, t, 0, 0, 0);
+                        }
                     }
                 }
                 fb_st<f32x4>(lds, vpark, 0, accp);
@@ -798,6 +884,19 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             asm volatile("" : "+v"(t3));
             const int r = t3 & 15, ox = tx0 + 16 * (wave & 1) + 4 * ((t3 & 63) >> 4), oy0 = ty0 + 2 * (wave >> 1);
             acc2[1][CT - 1] = fb_ld<f32x4>(lds, vpark, 0);
+            if constexpr (YCL) {
+                // lane (pixel r, g) holds channels 16 c + 4 g + e of its two pixels: 16-byte stores, channel-last
+                float* yt = Y + (long)tile * (a.C * 256L) + 4 * ((t3 & 63) >> 4);
+                const unsigned px = (unsigned)((2 * (wave >> 1)) * FB_TW + 16 * (wave & 1) + r);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if (16 * c >= a.C) continue;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        *reinterpret_cast<f32x4*>(yt + (px + q * FB_TW) * a.C + 16 * c) =
+                            (f32x4){acc2[q][c][0] * a.inv_s2, acc2[q][c][1] * a.inv_s2, acc2[q][c][2] * a.inv_s2, acc2[q][c][3] * a.inv_s2};
+                }
+            } else
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 const int co = 16 * c + r;
@@ -807,11 +906,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                     if (oy0 + q >= a.H) continue;
                     const float4 v = make_float4(acc2[q][c][0] * a.inv_s2, acc2[q][c][1] * a.inv_s2,
                                                  acc2[q][c][2] * a.inv_s2, acc2[q][c][3] * a.inv_s2);
-                    if (a.y_tm)
-                        *reinterpret_cast<float4*>(Y + (long)tile * (a.C * 256L) + co * 256 + (2 * (wave >> 1) + q) * FB_TW +
-                                                   16 * (wave & 1) + 4 * ((t3 & 63) >> 4)) = v;
-                    else
-                        *reinterpret_cast<float4*>(Y + (long)co * plane + (long)(oy0 + q) * a.W + ox) = v;
+                    *reinterpret_cast<float4*>(Y + (long)co * plane + (long)(oy0 + q) * a.W + ox) = v;
                 }
             }
         }
@@ -826,7 +921,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
 #endif
 }
 
-template <int KS, int CT, bool GATE = true, bool APPLY = false>
+template <int KS, int CT, bool GATE = true, bool APPLY = false, bool YCL = false>
 static int gdfn_launch(FusedArgs a, int B, hipStream_t stream) {
     const size_t lds = ((size_t)2 * FB_PLF + 2 * (KS * 1024 + 512) + (GATE ? CT * 512 + 2048 : 0)) * sizeof(float);
     static_assert(((size_t)2 * FB_PLF + 2 * (KS * 1024 + 512) + CT * 512 + 2048) * sizeof(float) <= 160 * 1024, "LDS");
@@ -834,7 +929,7 @@ static int gdfn_launch(FusedArgs a, int B, hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return IRM_ELAUNCH;
     if (!configured_dev[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lnpw_dw_fused_kernel<KS, CT, GATE, APPLY>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lnpw_dw_fused_kernel<KS, CT, GATE, APPLY, YCL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return IRM_ELAUNCH;
         configured_dev[dev] = 1;
@@ -852,7 +947,7 @@ static int gdfn_launch(FusedArgs a, int B, hipStream_t stream) {
     const int per = (a.items + 7) >> 3;
     a.gpx = (cus_dev[dev] + 7) / 8;
     if (a.gpx > per) a.gpx = per;
-    hipLaunchKernelGGL((lnpw_dw_fused_kernel<KS, CT, GATE, APPLY>), dim3(a.gpx * 8), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((lnpw_dw_fused_kernel<KS, CT, GATE, APPLY, YCL>), dim3(a.gpx * 8), dim3(512), lds, stream, a);
     return irm_launch_status();
 }
 
@@ -906,6 +1001,13 @@ extern "C" int irm_attn_gdfn_fused_f16x3_f32(const float* rec, const float* w2, 
     a.dbg = getenv("FB_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FB_DBG_PTR"), nullptr, 0) : nullptr;
 #endif
     a.tiles_x = 0; a.tiles = 0;
+    if (a.y_tm) {
+        if (bias2 && !irm_aligned16(bias2)) return IRM_EINVAL;
+        if (ks == 3) return gdfn_launch<3, 6, true, true, true>(a, B, stream);
+        if (ks == 2) return ct <= 3 ? gdfn_launch<2, 3, true, true, true>(a, B, stream) : gdfn_launch<2, 4, true, true, true>(a, B, stream);
+        if (ks == 1) return gdfn_launch<1, 2, true, true, true>(a, B, stream);
+        return IRM_EINVAL;
+    }
     if (ks == 3) return gdfn_launch<3, 6, true, true>(a, B, stream);
     if (ks == 2) return ct <= 3 ? gdfn_launch<2, 3, true, true>(a, B, stream) : gdfn_launch<2, 4, true, true>(a, B, stream);
     if (ks == 1) return gdfn_launch<1, 2, true, true>(a, B, stream);

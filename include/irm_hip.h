@@ -208,11 +208,12 @@ int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long x_bs, floa
  * at channels [2C, 3C) as before.  q, k are read by the Gram pass only (irm_mdta_gram_tm_f16x3_f32): a stage of that pass
  * then reads 2c row segments 1 KiB apart inside one contiguous block instead of 2c segments a plane apart.
  * H % 8 == 0, W % 32 == 0, C % 16 == 0.
- * Tile-major activations inside a stage (x_tm / v_tm / the `lay` bits of irm_attn_gdfn_fused_f16x3_f32): element
- * (channel, y, x) of an image's Cb-channel tensor at ((y >> 3) (W / 32) + (x >> 5)) Cb 256 + channel 256 + (y & 7) 32 + (x & 31):
- * an 8 x 32 tile's pixels of all channels form ONE contiguous block, so the stores of a work item and the reads of its
- * interior stay inside one block (the planar layout spreads them over Cb planes).  x_tm: x is read in that layout (Cb = C);
- * v_tm: v is written in it inside channels [2C, 3C) of y (Cb = C).  The first kernel of a stage reads planar, the last writes planar. */
+ * Tile-major channel-LAST activations inside a stage (x_tm / v_tm / the `lay` bits of irm_attn_gdfn_fused_f16x3_f32): element
+ * (channel, y, x) of an image's Cb-channel tensor at (((y >> 3) (W / 32) + (x >> 5)) 256 + (y & 7) 32 + (x & 31)) Cb + channel:
+ * a pixel's channels are contiguous (a lane fetches the 8 channels of a k-step as two 16-byte loads, every fetched line is
+ * used whole - the planar 34-pixel halo rows start one pixel before a line boundary) and an 8 x 32 tile is ONE contiguous
+ * Cb KiB block.  x_tm: x is read in that layout (Cb = C); v_tm: v is written in it inside channels [2C, 3C) of y (Cb = C).
+ * The first kernel of a stage reads planar, the last writes planar. */
 int irm_qkv_dw_fused_tm_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode, float eps,
                                   float inv_s1, int B, int C, int H, int W, int x_tm, int v_tm, irm_stream_t stream);
 /* irm_attn_gdfn_fused_f16x3_f32 (round 3): the last step of the attention branch inside the GDFN kernel's prologue,

@@ -130,14 +130,15 @@ def test_attn_gdfn_fused(dev, C, hid, H, W, B, ln, bias):
 
 
 def to_tm(t):
-    """[B][C][H][W] planar -> the same container holding the tile-major order of include/irm_hip.h ([tile][C][8 x 32])."""
+    """[B][C][H][W] planar -> the same container holding the tile-major channel-last order of include/irm_hip.h
+    ([tile][8 x 32 pixels][C])."""
     B, C, H, W = t.shape
-    return t.reshape(B, C, H // 8, 8, W // 32, 32).permute(0, 2, 4, 1, 3, 5).reshape(B, C, H, W).contiguous()
+    return t.reshape(B, C, H // 8, 8, W // 32, 32).permute(0, 2, 4, 3, 5, 1).reshape(B, C, H, W).contiguous()
 
 
 def from_tm(t):
     B, C, H, W = t.shape
-    return t.reshape(B, H // 8, W // 32, C, 8, 32).permute(0, 3, 1, 4, 2, 5).reshape(B, C, H, W).contiguous()
+    return t.reshape(B, H // 8, W // 32, 8, 32, C).permute(0, 5, 1, 3, 2, 4).reshape(B, C, H, W).contiguous()
 
 
 @pytest.mark.parametrize("C,hid,H,W,B,lay", [(96, 255, 16, 64, 2, 7), (96, 255, 24, 32, 1, 1), (48, 127, 8, 96, 3, 2),
