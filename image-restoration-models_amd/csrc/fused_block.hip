@@ -188,7 +188,9 @@ __device__ __forceinline__ void fb_dma(const float* src, float* dst, int wave, i
 // YCL (APPLY only): y is written in the tile-major channel-last layout (FusedArgs).  project_out then runs with its
 // operands swapped (weights = A: the MFMA leaves lane (pixel, g) with channels 16 c + 4 g + e - 16-byte stores), and the
 // residual x' reaches the accumulators through a pixel-major LDS image instead of the transposed one.
-template <int KS, int CT, bool GATE, bool APPLY = false, bool YCL = false>
+// XVCL: x (and v) are channel-last at compile time - the instantiation of the blocks inside a stage carries no planar load
+// path (its 24 + 24 plane base addresses live in scalar registers across the item loop and spill into vector lanes).
+template <int KS, int CT, bool GATE, bool APPLY = false, bool YCL = false, bool XVCL = false>
 __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
     static_assert(!APPLY || GATE, "APPLY is a variant of the GDFN kernel");
     static_assert(!YCL || APPLY, "YCL is a variant of the APPLY kernel");
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             const int ty0 = (tile / a.tiles_x) * FB_TH, tx0 = (tile % a.tiles_x) * FB_TW;
             const float* X = a.X + (long)b * a.x_bs;
             const long plane = (long)a.H * a.W;
-            if (a.x_tm) {                                  // tile-major, channel-last: two 16-byte loads per k-step
+            if (XVCL || a.x_tm) {                          // tile-major, channel-last: two 16-byte loads per k-step
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const int p = 16 * (wave + 8 * j) + r2, ph = p / FB_HC, pc = p - ph * FB_HC;
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                 }
                 return;
             }
+            if constexpr (!XVCL)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int p = 16 * (wave + 8 * j) + r2, ph = p / FB_HC, pc = p - ph * FB_HC;
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
             const int ty0 = (tile / a.tiles_x) * FB_TH, tx0 = (tile % a.tiles_x) * FB_TW;
             const float* V = a.V + (long)b * a.v_bs;
             const long plane = (long)a.H * a.W;
-            if (a.v_tm) {
+            if (XVCL || a.v_tm) {
 #pragma unroll
                 for (int j = 0; j < (APPLY ? 3 : 0); ++j) {
                     const int p = 16 * (wave + 8 * j) + r2, ph = p / FB_HC, pc = p - ph * FB_HC;
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
                 }
                 return;
             }
+            if constexpr (!XVCL)
 #pragma unroll
             for (int j = 0; j < (APPLY ? 3 : 0); ++j) {
                 const int p = 16 * (wave + 8 * j) + r2, ph = p / FB_HC, pc = p - ph * FB_HC;
@@ -921,7 +925,7 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
 #endif
 }
 
-template <int KS, int CT, bool GATE = true, bool APPLY = false, bool YCL = false>
+template <int KS, int CT, bool GATE = true, bool APPLY = false, bool YCL = false, bool XVCL = false>
 static int gdfn_launch(FusedArgs a, int B, hipStream_t stream) {
     const size_t lds = ((size_t)2 * FB_PLF + 2 * (KS * 1024 + 512) + (GATE ? CT * 512 + 2048 : 0)) * sizeof(float);
     static_assert(((size_t)2 * FB_PLF + 2 * (KS * 1024 + 512) + CT * 512 + 2048) * sizeof(float) <= 160 * 1024, "LDS");
@@ -929,7 +933,7 @@ static int gdfn_launch(FusedArgs a, int B, hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return IRM_ELAUNCH;
     if (!configured_dev[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lnpw_dw_fused_kernel<KS, CT, GATE, APPLY, YCL>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lnpw_dw_fused_kernel<KS, CT, GATE, APPLY, YCL, XVCL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return IRM_ELAUNCH;
         configured_dev[dev] = 1;
@@ -947,7 +951,7 @@ static int gdfn_launch(FusedArgs a, int B, hipStream_t stream) {
     const int per = (a.items + 7) >> 3;
     a.gpx = (cus_dev[dev] + 7) / 8;
     if (a.gpx > per) a.gpx = per;
-    hipLaunchKernelGGL((lnpw_dw_fused_kernel<KS, CT, GATE, APPLY, YCL>), dim3(a.gpx * 8), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((lnpw_dw_fused_kernel<KS, CT, GATE, APPLY, YCL, XVCL>), dim3(a.gpx * 8), dim3(512), lds, stream, a);
     return irm_launch_status();
 }
 
@@ -1001,6 +1005,12 @@ extern "C" int irm_attn_gdfn_fused_f16x3_f32(const float* rec, const float* w2, 
     a.dbg = getenv("FB_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FB_DBG_PTR"), nullptr, 0) : nullptr;
 #endif
     a.tiles_x = 0; a.tiles = 0;
+#ifndef FB_NO_XVCL          // (variant build for A/B: the general instantiations with run-time layout flags only)
+    if (a.x_tm && a.v_tm && ks == 3) return a.y_tm ? ((bias2 && !irm_aligned16(bias2)) ? IRM_EINVAL : gdfn_launch<3, 6, true, true, true, true>(a, B, stream))
+                                                   : gdfn_launch<3, 6, true, true, false, true>(a, B, stream);
+    if (a.x_tm && a.v_tm && ks == 2 && ct <= 3) return a.y_tm ? ((bias2 && !irm_aligned16(bias2)) ? IRM_EINVAL : gdfn_launch<2, 3, true, true, true, true>(a, B, stream))
+                                                              : gdfn_launch<2, 3, true, true, false, true>(a, B, stream);
+#endif
     if (a.y_tm) {
         if (bias2 && !irm_aligned16(bias2)) return IRM_EINVAL;
         if (ks == 3) return gdfn_launch<3, 6, true, true, true>(a, B, stream);
@@ -1028,6 +1038,12 @@ static int qkv_dw_fused(const float* rec, const float* x, long x_bs, float* y, l
     a.dbg = getenv("FB_DBG_PTR") ? (unsigned long long*)strtoull(getenv("FB_DBG_PTR"), nullptr, 0) : nullptr;
 #endif
     a.tiles_x = 0; a.tiles = 0;
+#ifndef FB_NO_XVCL
+    if (a.x_tm) {            // the blocks inside a stage: no planar load path in the instantiation
+        if ((C + 31) / 32 == 3) return gdfn_launch<3, 1, false, false, false, true>(a, B, stream);
+        if ((C + 31) / 32 == 2) return gdfn_launch<2, 1, false, false, false, true>(a, B, stream);
+    }
+#endif
     switch ((C + 31) / 32) {
         case 3: return gdfn_launch<3, 1, false>(a, B, stream);
         case 2: return gdfn_launch<2, 1, false>(a, B, stream);

@@ -19,7 +19,9 @@ for C, hid, H, W, B in [(96, 255, 512, 512, 6), (48, 127, 512, 512, 6)]:
                                r("c", (C, hid), -.3, .3), r("d", (C,), .5, 1.5), r("e", (C,), -.2, .2), kperm=True)
     frag = _hip.pack_mfold_frag(r("m", (B, C, C), -.2, .2)).to(dev)
     for name, fn in (("gdfn", lambda: ops.gdfn_fused(pk, x, y, C, hid, ln_mode=1)), ("qkv", lambda: ops.qkv_dw_fused(pkq, x, yq, C, 3 * C, ln_mode=1)),
-                     ("attn_gdfn", lambda: ops.attn_gdfn_fused(pka, x, yq[:, 2 * C:], frag, y, C, hid, ln_mode=1))):
+                     ("attn_gdfn", lambda: ops.attn_gdfn_fused(pka, x, yq[:, 2 * C:], frag, y, C, hid, ln_mode=1)),
+                     ("qkv tile-major (q, k; x, v channel-last)", lambda: ops.qkv_dw_fused(pkq, x, yq, C, 3 * C, ln_mode=1, tm=True, x_tm=True, v_tm=True)),
+                     ("attn_gdfn channel-last x, v, y", lambda: ops.attn_gdfn_fused(pka, x, yq[:, 2 * C:], frag, y, C, hid, ln_mode=1, x_tm=True, v_tm=True, y_tm=True))):
         for _ in range(3):
             fn()
         torch.cuda.synchronize(); dbg.zero_(); fn(); torch.cuda.synchronize()
