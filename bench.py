@@ -180,11 +180,15 @@ def pmc_step_totals():
 
 #: timer group -> (kernel label, roofline that bounds it, regex of its instantiations in the PMC table)
 ROOFLINE_KERNELS = {
+    "attn_gdfn_fused": ("lnpw_dw_fused_kernel<GATE, APPLY> (irm_attn_gdfn_fused_f16x3_f32: x' = x + project_out(attn @ v) by the folded "
+                        "per-image matrix, then LayerNorm + project_in + depth-wise 3x3 + GELU gate + project_out + residual, in one "
+                        "kernel; 1x1 convs = fp32 emulated by three fp16 MFMAs)", "mfma",
+                        r"^lnpw_dw_fused_kernel<\d+, \d+, true, true"),
     "gdfn_fused": ("lnpw_dw_fused_kernel<GATE> (irm_gdfn_fused_f16x3_f32: LayerNorm + project_in + depth-wise 3x3 + GELU gate + "
                    "project_out + residual in one kernel; 1x1 convs = fp32 emulated by three fp16 MFMAs)", "mfma",
-                   r"^lnpw_dw_fused_kernel<.*, true>"),
-    "qkv_dw_fused": ("lnpw_dw_fused_kernel<!GATE> (irm_qkv_dw_fused_f16x3_f32: LayerNorm + qkv 1x1 + depth-wise 3x3)", "hbm",
-                     r"^lnpw_dw_fused_kernel<.*, false>"),
+                   r"^lnpw_dw_fused_kernel<\d+, \d+, true, false"),
+    "qkv_dw_fused": ("lnpw_dw_fused_kernel<!GATE> (irm_qkv_dw_fused[_tm]_f16x3_f32: LayerNorm + qkv 1x1 + depth-wise 3x3)", "hbm",
+                     r"^lnpw_dw_fused_kernel<\d+, \d+, false"),
     "gemm1x1_f16x3": ("gemm_xres_kernel / gemm_ring_kernel<F16> (irm_gemm1x1_f16x3_f32: LayerNorm + 1x1 conv, fp32 emulated "
                       "by three fp16 MFMAs, fp32 accumulate)", "hbm", r"^(gemm_ring_kernel<.*, true>|gemm_xres_kernel)"),
     "gemm_ps_f16x3": ("gemm_ps_kernel (irm_gemm_presplit_f16x3_f32: 1x1 conv on pre-split fp16 hi/lo fragments of LayerNorm(x), "
@@ -360,7 +364,7 @@ def main():
             dom = max(ks, key=lambda k: ks[k]["ms"])
             g = ks[dom]
             label, bound, pmc_re = ROOFLINE_KERNELS.get(dom, (dom, "hbm", None))
-            emulated = dom in ("gdfn_fused", "qkv_dw_fused", "gemm1x1_f16x3", "dwgemm_f16x3", "gemm_ps_f16x3")
+            emulated = dom in ("attn_gdfn_fused", "gdfn_fused", "qkv_dw_fused", "gemm1x1_f16x3", "dwgemm_f16x3", "gemm_ps_f16x3")
             if bound == "mfma" and emulated:
                 # the unit that executes the arithmetic is the fp16 matrix core: three MFMA passes per fp32 product
                 ach, peak, unit = 3.0 * g["flops"] / (g["ms"] * 1e-3) / 1e12, PEAK_F16_MFMA_TFLOPS, "TFLOP/s"
@@ -382,15 +386,18 @@ def main():
                                "launches": g["launches"],
                                "avg_launch_us": g["ms"] * 1e3 / g["launches"],
                                "share_of_kernel_time": g["ms"] / tot_ms}
-            if dom == "gdfn_fused":
+            if dom in ("gdfn_fused", "attn_gdfn_fused"):
                 # second view, clearly separate from `achieved`: SURVEY 8(d) counts the bytes at the REFERENCE's op
                 # boundaries; the rows this one kernel replaces are LN + project_in (1 + 2r), dwconv + gate (3r) and
-                # project_out + residual (r + 2) tensors of C N floats, r = hid / C = 255 / 96 (127 / 48 at C = 48): (3 + 6r) / 2 x its
-                # own 2 C N boundary.  The kernel's own boundary traffic is `achieved`'s basis under bound "hbm" only.
+                # project_out + residual (r + 2) tensors of C N floats, r = hid / C = 255 / 96 (127 / 48 at C = 48): (3 + 6r) C N
+                # (+ 3 C N for the attention branch's project_out + residual when that runs in this kernel as well).  The
+                # kernel's own boundary traffic is `achieved`'s basis under bound "hbm" only.
                 r_ = 255.0 / 96.0
-                ref_bytes = g["bytes"] / 2.0 * (3.0 + 6.0 * r_)       # own boundary (timer): x read (also the residual) + y written = 2 C N
+                own_cn = 3.0 if dom == "attn_gdfn_fused" else 2.0      # own boundary (timer): x (+ v) read, y written, in C N floats
+                ref_bytes = g["bytes"] / own_cn * (3.0 + 6.0 * r_ + (3.0 if dom == "attn_gdfn_fused" else 0.0))
                 out["roofline"]["reference_rows"] = {
-                    "rows": "R1 LayerNorm + R2 project_in + R3 depth-wise 3x3 + R5 gate + R2 project_out + residual (SURVEY 8a)",
+                    "rows": ("R2 attention project_out + residual + " if dom == "attn_gdfn_fused" else "") +
+                            "R1 LayerNorm + R2 project_in + R3 depth-wise 3x3 + R5 gate + R2 project_out + residual (SURVEY 8a)",
                     "survey_bytes_per_launch": ref_bytes / g["launches"],
                     "gbs": ref_bytes / (g["ms"] * 1e-3) / 1e9,
                     "frac_of_hbm_peak": ref_bytes / (g["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,

@@ -226,6 +226,9 @@ __global__ __launch_bounds__(512, 2) void lnpw_dw_fused_kernel(FusedArgs a) {
     int round = 0;
     int item = item_of(0);
     if (item >= a.items) return;
+#ifdef FB_STAGGER      // experiment (variant build): workgroups start FB_STAGGER x 64 cycles apart in 8 phases
+    for (int d = 0; d < (int)((blockIdx.x >> 3) & 7) * FB_STAGGER; ++d) __builtin_amdgcn_s_sleep(1);
+#endif
     float xr[3][KS][8];
 
     for (;;) {
