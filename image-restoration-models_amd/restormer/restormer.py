@@ -396,29 +396,33 @@ class Restormer(nn.Module):
         return alt
 
     def _run_stage(self, name, pk, x, have_stats=False):
-        blocks = getattr(self, name)
+        """The TransformerBlocks of one stage (or of several consecutive stages on the same tensor: a tuple of names), in
+        place on x."""
+        names = (name,) if isinstance(name, str) else tuple(name)
+        blocks = [(f"{n}.{i}", blk) for n in names for i, blk in enumerate(getattr(self, n))]
         B, C, H, W = x.shape
-        if (len(blocks) and "gdfn_f" in pk[f"{name}.0"] and ops.can_fuse_gdfn(C, W) and (H * W) % 4 == 0
-                and not os.environ.get("IRM_NO_FUSE_BLOCK")):
+        if (len(blocks) and all("gdfn_f" in pk[k] for k, _ in blocks) and ops.can_fuse_gdfn(C, W) and (H * W) % 4 == 0
+                and len({blk.attn.num_heads for _, blk in blocks}) == 1 and not os.environ.get("IRM_NO_FUSE_BLOCK")):
             cur, alt = x, self._buf(f"alt_{C}", B * C * H * W, x.device).view(B, C, H, W)
-            # between the blocks of a stage x travels tile-major (include/irm_hip.h): the first block reads the planar
-            # stage input, the last one writes the planar stage output
-            heads = blocks[0].attn.num_heads
-            act_tm = (all("gdfn_fa" in pk[f"{name}.{i}"] and "gram_s" in pk[f"{name}.{i}"] for i in range(len(blocks)))
+            # between the blocks x travels tile-major channel-last (include/irm_hip.h): the first block reads the planar
+            # input, the last one writes the planar output
+            heads = blocks[0][1].attn.num_heads
+            act_tm = (all("gdfn_fa" in pk[k] and "gram_s" in pk[k] for k, _ in blocks)
                       and ops.can_qk_tile_major(C, heads, H, W) and not os.environ.get("IRM_NO_APPLY_FUSE")
                       and not os.environ.get("IRM_GRAM_EXACT") and not os.environ.get("IRM_NO_QK_TM")
                       and not os.environ.get("IRM_NO_ACT_TM"))
-            for i, blk in enumerate(blocks):
-                out = self._block_fused(blk, pk[f"{name}.{i}"], cur, alt, x_tm=act_tm and i > 0,
-                                        y_tm=act_tm and i + 1 < len(blocks))
+            for i, (k, blk) in enumerate(blocks):
+                out = self._block_fused(blk, pk[k], cur, alt, x_tm=act_tm and i > 0, y_tm=act_tm and i + 1 < len(blocks))
                 cur, alt = out, cur
-            if cur is not x:                           # odd number of blocks: the stage result belongs in x
+            if cur is not x:                           # odd number of blocks: the result belongs in x
                 x.copy_(cur)
                 if ops.TIMER is not None:
                     ops.TIMER.break_chain()
             return False
-        for i, blk in enumerate(blocks):
-            have_stats = self._block(blk, pk[f"{name}.{i}"], x, have_stats, want_stats=i + 1 < len(blocks))
+        for n in names:
+            stage = getattr(self, n)
+            for i, blk in enumerate(stage):
+                have_stats = self._block(blk, pk[f"{n}.{i}"], x, have_stats, want_stats=i + 1 < len(stage))
         return have_stats
 
     # ------------------------------------------------------------------ forward
@@ -470,8 +474,8 @@ class Restormer(nn.Module):
         ops.gemm1x1(pk["reduce_chan_level2"], cat2, dec2, d2, 2 * d2, bias=pk["reduce_chan_level2_b"])
         self._run_stage("decoder_level2", pk, dec2)
         ops.conv3x3(pk["up2_1"], dec2, cat1[:, :d1], d2, d2 * 2, store_mode=2)
-        self._run_stage("decoder_level1", pk, cat1)
-        self._run_stage("refinement", pk, cat1)          # (first block recomputes its statistics)
+        # (decoder_level1 and refinement work on the same tensor: one chain, no planar round trip between them)
+        self._run_stage(("decoder_level1", "refinement"), pk, cat1)
         tap = self.__dict__.get("_tap")
         if tap is not None:                              # test tap: the trunk output before the `output` conv
             tap["refinement"] = cat1.clone()
