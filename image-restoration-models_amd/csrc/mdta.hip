@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256, 2) void mdta_gram_ring_kernel(GramArgs a) {
     const int S = chunk_id < nblocks ? (nblocks - chunk_id + a.nchunk - 1) / a.nchunk : 0;
     const long sstep = (long)a.nchunk * BP;
 #endif
-    const float* base = a.qkv + (long)b * a.bs + nbeg;
+    // (a.tm: q, k tile-major, see mdta_gram_f16x3_kernel)
+    const float* base = a.qkv + (long)b * a.bs + (a.tm ? 0 : nbeg);
+    const long rowstride = a.tm ? 256 : a.N;
 
     // DMA sources of this lane: instruction j of this wave covers rows RPB*(4j + wave) ..; lane = rr*CPR + p
     // fetches piece (p - rot(row)) mod CPR of its row, rot(row) = row mod 16 (T = 3) or (row >> 1) mod 8
@@ -189,13 +191,18 @@ __global__ __launch_bounds__(256, 2) void mdta_gram_ring_kernel(GramArgs a) {
         const int row = RPB * (4 * j + wave) + lane / CPR, p = lane % CPR;
         const int rot = (T == 3 ? row : row >> 1) & (CPR - 1);
         const int ch = row < c ? head * c + row : a.C + head * c + (row - c);
-        src[j] = base + (long)ch * a.N + 4 * ((p - rot) & (CPR - 1));
+        src[j] = base + (long)ch * rowstride + 4 * ((p - rot) & (CPR - 1));
     }
     auto issue = [&](int s) {
         float* dst = smem + (s % NS) * STG + wave * 256;
+        long so = s * sstep;
+        if (a.tm) {
+            const long n0 = (long)nbeg + so;
+            so = (n0 >> 8) * (2L * a.C * 256) + (n0 & 255);
+        }
 #pragma unroll
         for (int j = 0; j < LPS; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + s * sstep),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + so),
                                              (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
         }
     };
@@ -556,6 +563,18 @@ static int launch_gram_ring(const GramArgs& a, int B, hipStream_t stream) {
     IRM_ALLOW_BIG_LDS((&mdta_gram_ring_kernel<T, NS>));
     hipLaunchKernelGGL((mdta_gram_ring_kernel<T, NS>), dim3(a.heads * a.nchunk, B), dim3(256), lds, stream, a);
     return irm_launch_status();
+}
+
+// The f32-input ring pass over tile-major q, k (header): c = 48 / 96, N % 256 == 0.
+extern "C" int irm_mdta_gram_tm_f32(const float* qkv, long bs, float* part, int B, int C, int heads, int N, int chunk,
+                                    hipStream_t stream) {
+    if (!qkv || !part || B <= 0 || C <= 0 || heads <= 0 || N <= 0 || chunk <= 0) return IRM_EINVAL;
+    if (C % heads || (chunk & 63) || B > 65535) return IRM_EINVAL;
+    const int c = C / heads;
+    if ((c != 48 && c != 96) || (N & 255) || (bs & 3) || !irm_aligned16(qkv)) return IRM_EINVAL;
+    if ((long)heads * ((N + chunk - 1) / chunk) > 2147483647L) return IRM_EINVAL;
+    GramArgs a{qkv, bs, part, C, heads, N, chunk, (N + chunk - 1) / chunk, 1};
+    return c == 48 ? launch_gram_ring<3>(a, B, stream) : launch_gram_ring<6>(a, B, stream);
 }
 
 extern "C" int irm_mdta_gram_f32(const float* qkv, long bs, float* part, int B, int C, int heads, int N,

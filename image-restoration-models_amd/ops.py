@@ -310,7 +310,7 @@ def attn_gdfn_fused(pk, x, v, mfold_frag, y, C: int, hid: int, *, ln_mode, bias_
 
 
 def can_qk_tile_major(C: int, heads: int, H: int, W: int) -> bool:
-    """q, k tile-major (qkv_dw_fused(tm=True) -> mdta_fold(tm=True)): whole 8 x 32 tiles and the f16x3 ring Gram pass."""
+    """q, k tile-major (qkv_dw_fused(tm=True) -> mdta_fold(tm=True)): whole 8 x 32 tiles and an LDS-DMA ring Gram pass."""
     return C % 16 == 0 and C % heads == 0 and C // heads in (48, 96) and H % 8 == 0 and W % 32 == 0
 
 
@@ -372,16 +372,16 @@ def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, att
     chunk, nchunk, rec = mdta_plan(B, C, heads, N)
     assert part.numel() >= B * heads * nchunk * rec and gsum.numel() >= B * heads * rec
     c = C // heads
-    assert not tm or (gram_scale is not None and c in (48, 96) and N % 256 == 0), "tile-major q, k: f16x3 ring pass only"
-    if gram_scale is not None and c in (48, 96) and N % 64 == 0 and (tm or not os.environ.get("IRM_GRAM_EXACT")):
+    assert not tm or (c in (48, 96) and N % 256 == 0), "tile-major q, k: the LDS-DMA ring passes only"
+    if gram_scale is not None and c in (48, 96) and N % 64 == 0 and not os.environ.get("IRM_GRAM_EXACT"):
         assert gram_scale.numel() == 2 * C and gram_scale.is_contiguous()
         _launch("mdta_gram_f16x3", 2.0 * B * heads * c * c * N, 8.0 * B * C * N,
                 "irm_mdta_gram_tm_f16x3_f32" if tm else "irm_mdta_gram_f16x3_f32", _hip.ptr(qkv),
                 _bs(qkv), _hip.ptr(gram_scale), _hip.ptr(part), B, C, heads, N, chunk,
                 tag=f"C{C} h{heads} N{N} B{B} chunk{chunk}")
     else:
-        _launch("mdta_gram", 2.0 * B * heads * c * c * N, 8.0 * B * C * N, "irm_mdta_gram_f32", _hip.ptr(qkv), _bs(qkv),
-                _hip.ptr(part), B, C, heads, N, chunk, tag=f"C{C} h{heads} N{N} B{B} chunk{chunk}")
+        _launch("mdta_gram", 2.0 * B * heads * c * c * N, 8.0 * B * C * N, "irm_mdta_gram_tm_f32" if tm else "irm_mdta_gram_f32",
+                _hip.ptr(qkv), _bs(qkv), _hip.ptr(part), B, C, heads, N, chunk, tag=f"C{C} h{heads} N{N} B{B} chunk{chunk}")
     _launch("mdta_finalize", 2.0 * B * C * C * c, 4.0 * B * (heads * nchunk * rec + C * C),
             "irm_mdta_finalize_frag_f16x3_f32" if frag else "irm_mdta_finalize_f16x3_f32" if split else "irm_mdta_finalize_f32",
             _hip.ptr(part), _hip.ptr(gsum), _hip.ptr(temperature), _hip.ptr(wout), _hip.ptr(mfold), _hip.ptr(attn),

@@ -364,8 +364,7 @@ class Restormer(nn.Module):
         heads, hid = blk.attn.num_heads, blk.ffn.hidden
         qkv = self._buf("scratch_a", B * 3 * C * N, dev).view(B, 3 * C, H, W)
         # q, k tile-major for the Gram pass (its only reader) where the f16x3 ring pass runs on whole tiles
-        tm = ("gram_s" in w and ops.can_qk_tile_major(C, heads, H, W) and not os.environ.get("IRM_GRAM_EXACT")
-              and not os.environ.get("IRM_NO_QK_TM"))
+        tm = ops.can_qk_tile_major(C, heads, H, W) and not os.environ.get("IRM_NO_QK_TM")
         fa = "gdfn_fa" in w and not os.environ.get("IRM_NO_APPLY_FUSE")
         assert not (x_tm or y_tm) or (tm and fa), "tile-major x / y: only between the kernels that understand them"
         v_tm = tm and fa and not os.environ.get("IRM_NO_ACT_TM")
@@ -407,9 +406,8 @@ class Restormer(nn.Module):
             # between the blocks x travels tile-major channel-last (include/irm_hip.h): the first block reads the planar
             # input, the last one writes the planar output
             heads = blocks[0][1].attn.num_heads
-            act_tm = (all("gdfn_fa" in pk[k] and "gram_s" in pk[k] for k, _ in blocks)
-                      and ops.can_qk_tile_major(C, heads, H, W) and not os.environ.get("IRM_NO_APPLY_FUSE")
-                      and not os.environ.get("IRM_GRAM_EXACT") and not os.environ.get("IRM_NO_QK_TM")
+            act_tm = (all("gdfn_fa" in pk[k] for k, _ in blocks) and ops.can_qk_tile_major(C, heads, H, W)
+                      and not os.environ.get("IRM_NO_APPLY_FUSE") and not os.environ.get("IRM_NO_QK_TM")
                       and not os.environ.get("IRM_NO_ACT_TM"))
             for i, (k, blk) in enumerate(blocks):
                 out = self._block_fused(blk, pk[k], cur, alt, x_tm=act_tm and i > 0, y_tm=act_tm and i + 1 < len(blocks))

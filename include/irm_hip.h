@@ -252,6 +252,9 @@ int irm_mdta_gram_f16x3_f32(const float* qkv, long bs, const float* scale, float
 /* The same pass over q, k in the tile-major order of irm_qkv_dw_fused_tm_f16x3_f32 (N % 256 == 0; v is not read). */
 int irm_mdta_gram_tm_f16x3_f32(const float* qkv, long bs, const float* scale, float* part, int B, int C, int heads, int N,
                             int chunk, irm_stream_t stream);
+/* ... and the f32-input ring pass (no operand scales: any LayerNorm flavour) over tile-major q, k: c = 48 / 96, N % 256 == 0. */
+int irm_mdta_gram_tm_f32(const float* qkv, long bs, float* part, int B, int C, int heads, int N, int chunk,
+                         irm_stream_t stream);
 
 /* MDTA pass 2: reduce the partials (gsum: workspace [B][heads][c*c+2c]),
  * softmax((G_ij / (max(|q_i|,1e-12) max(|k_j|,1e-12))) * temperature[head]) and

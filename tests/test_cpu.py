@@ -433,6 +433,41 @@ def test_presplit_host_side_packing_and_plans():
     assert _hip.plan_presplit(64, 6144, 192) == (4, 1, 43) and _hip.plan_presplit(128, 1536, 384) == (8, 4, 81)
 
 
+def test_apply_fusion_host_side_packing():
+    """Host side of irm_attn_gdfn_fused_f16x3_f32: the folded-matrix fragments round trip (hi + lo = the fp16x2 value,
+    zero K / M padding), and pack_gdfn_fused(kperm=True) holds the same project_in weights with its input channels in
+    the order the apply MFMA leaves x' in the registers (k-slot 32 ks + 8 g + j <-> channel 16 (2 ks + (j >> 2)) + 4 g + (j & 3))."""
+    for B, C in ((2, 96), (3, 48), (1, 64)):
+        m = gin(f"mf{C}", (B, C, C), -0.4, 0.4)
+        frag = _hip.pack_mfold_frag(m)
+        KS = (C + 31) // 32
+        assert frag.numel() == B * 2 * KS * KS * 512
+        hi = m.half().float()
+        assert torch.equal(_hip.unpack_mfold_frag(frag, B, C), hi + (m - hi).half().float())
+        h = frag.view(torch.float16).view(B, 2 * KS, KS, 2, 4, 16, 8).float()          # [t][ks][hi|lo][g][m][e]
+        full = (h[:, :, :, 0] + h[:, :, :, 1]).permute(0, 1, 4, 2, 3, 5).reshape(B, 32 * KS, 32 * KS)
+        assert float(full[:, C:].abs().max() if C < 32 * KS else 0.0) == 0.0 and float(full[:, :, C:].abs().max() if C < 32 * KS else 0.0) == 0.0
+    C, hid = 96, 255
+    args = (gin("kp1", (2 * hid, C), -0.3, 0.3), None, gin("kp2", (2 * hid, 9), -0.4, 0.4), None, gin("kp3", (C, hid), -0.3, 0.3),
+            gin("kp4", (C,), 0.5, 1.5), gin("kp5", (C,), -0.2, 0.2))
+    rec0, w20, i10, i20 = _hip.pack_gdfn_fused(*args)
+    rec1, w21, i11, i21 = _hip.pack_gdfn_fused(*args, kperm=True)
+    assert torch.equal(w20, w21) and (i10, i20) == (i11, i21)
+    S, KS = (hid + 15) // 16, 3
+    r0 = rec0.view(S + 1, KS * 1024 + 512)
+    r1 = rec1.view(S + 1, KS * 1024 + 512)
+    assert torch.equal(r0[:, KS * 1024:], r1[:, KS * 1024:])                              # taps, biases: unchanged
+    # [S][hct][KS][hi|lo][g][m][8 j] halves -> [.., channel slot 32 ks + 8 g + j]
+    def slots(r):
+        h = r[:S, :KS * 1024].contiguous().view(torch.float16).view(S, 2, KS, 2, 4, 16, 8)
+        return h.permute(0, 1, 3, 5, 2, 4, 6).reshape(S, 2, 2, 16, 32 * KS)
+    slot = torch.arange(32 * KS)
+    ks_, g_, j_ = slot // 32, (slot % 32) // 8, slot % 8
+    chan = 16 * (2 * ks_ + (j_ >> 2)) + 4 * g_ + (j_ & 3)
+    assert sorted(chan.tolist()) == list(range(32 * KS))
+    assert torch.equal(slots(r1), slots(r0)[..., chan])
+
+
 def test_fullsize_frame_fixture_is_self_consistent():
     """tests/golden/restormer_fullsize_frame.npz (the reference's run_model_inference on bench frame 0): the stored
     sha256 and PSNR are those of the stored uint8 frame against the regenerated synthetic target, and the input it

@@ -229,8 +229,9 @@ def test_qkv_dw_fused(dev, C, H, W, B, ln, bias):
     assert torch.all(y[:, 0] == 7.0) and torch.all(y[:, M + 1] == 7.0), "wrote outside its channel slice"
 
 
-@pytest.mark.parametrize("C,heads,H,W,B", [(96, 1, 16, 64, 2), (96, 2, 24, 32, 1), (48, 1, 8, 96, 3), (96, 1, 40, 64, 1)])
-def test_qk_tile_major_chain(dev, C, heads, H, W, B):
+@pytest.mark.parametrize("C,heads,H,W,B,f16", [(96, 1, 16, 64, 2, True), (96, 2, 24, 32, 1, True), (48, 1, 8, 96, 3, True),
+                                               (96, 1, 40, 64, 1, True), (96, 2, 16, 64, 2, False), (48, 1, 16, 32, 1, False)])
+def test_qk_tile_major_chain(dev, C, heads, H, W, B, f16):
     """qkv_dw_fused(tm) + Gram pass (tm): q, k tile-major [tile][2C][256] - v, the attention matrix and the folded matrix
     as with planar q, k (the Gram sum runs over the same pixels in another order: a few ulps)."""
     tag = f"tm{C}_{heads}_{H}_{W}"
@@ -239,7 +240,8 @@ def test_qk_tile_major_chain(dev, C, heads, H, W, B):
     lnw, lnb = rnd(tag + "lw", (C,), 0.5, 1.5), rnd(tag + "lb", (C,), -0.2, 0.2)
     w, dw_w = rnd(tag + "w", (M, C), -0.3, 0.3), rnd(tag + "dw", (M, 9), -0.4, 0.4)
     pk = _hip.pack_qkv_fused(w.to(dev), None, dw_w, None, lnw, lnb)
-    gs = _hip.gram_scales(w.view(M, C, 1, 1), None, dw_w.view(M, 1, 3, 3), None, lnw, lnb, True).to(dev)
+    # (f16: the Gram pass emulated on the fp16 matrix cores; else the f32-input ring pass, as under a BiasFree LayerNorm)
+    gs = _hip.gram_scales(w.view(M, C, 1, 1), None, dw_w.view(M, 1, 3, 3), None, lnw, lnb, True).to(dev) if f16 else None
     temp, wout = rnd(tag + "t", (heads,), 2.0, 6.0).to(dev), rnd(tag + "wo", (C, C), -0.3, 0.3).to(dev)
     res = []
     for tm in (False, True, 2):
