@@ -50,9 +50,15 @@ struct ConvF16Args {
 template <int N>
 __device__ __forceinline__ void cf_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int CT>
+// NCH (round 3): a pass covers NCH chunks of CT output tiles (accumulators for all of them in registers: 8 CT NCH), so the
+// input tile of a stage is fetched and converted ONCE per NCH x CT output tiles instead of once per CT - the up-sampling
+// convs (Co = 2 Ci = 192 / 384 / 768: 12 / 24 / 48 output tiles) ran 3 / 6 / 4 passes over the same input.  The weights of a
+// tap group still cover CT tiles (the LDS bound): NCH x 3 groups per stage instead of 3.
+template <int CT, int NCH = 1>
 __global__ __launch_bounds__(512, 2) void conv3x3_f16x3_kernel(ConvF16Args a) {
     IRM_KERNEL_ENTRY();
+    constexpr int TT = CT * NCH;                   // output tiles per pass
+    constexpr int NG = 3 * NCH;                    // weight groups per stage
     constexpr int WGB = 3 * CT * 2048;             // bytes of the weights of one tap group (3 taps)
     constexpr int NW = (WGB / 16 + 511) / 512;     // weight DMA instructions per lane and tap group
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16x3_kernel(ConvF16Args a) {
     const float* X = a.X + (long)b * a.x_bs;
     const long plane = (long)a.H * a.W;
     const int S = a.S;
-    const int nchunks = (a.mtiles + CT - 1) / CT;
+    const int nchunks = (a.mtiles + TT - 1) / TT;
     const int my_chunks = (nchunks - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
 
     // raw DMA geometry of this lane (fixed over stages): chunk q = j * 512 + tid -> (channel, row, 16-byte column chunk)
@@ -93,31 +99,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16x3_kernel(ConvF16Args a) {
                                              (__attribute__((address_space(3))) void*)(raw + (j * 512 + wave * 64) * 16), 16, 0, 0);
         }
     };
-    // tap group n = 3 s + tg (3 taps x CT tiles x hi|lo x 1 KiB) -> buffer n & 1
+    // weight group n = (s NCH + chunk) 3 + tg (3 taps x CT tiles x hi|lo x 1 KiB) -> buffer n & 1
     auto issue_w = [&](int mt0, int n) {
-        const int s = n / 3, tg = n - 3 * s;
+        const int sc = n / 3, tg = n - 3 * sc, s = sc / NCH, chn = sc - s * NCH;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const int cb = min(j * 512 + wave * 64, WGB / 16 - 64);          // surplus waves repeat the last 1 KiB (same bytes)
             const int q = cb + lane;
             const int ct = q / 384, rem = q - ct * 384;                       // 384 chunks = 3 taps x (hi | lo) x 1 KiB per output tile
-            const int mt = min(mt0 + ct, a.mtiles - 1);
+            const int mt = min(mt0 + chn * CT + ct, a.mtiles - 1);
             const float* src = a.Wp + ((((long)mt * S + s) * 9 + tg * 3) * 2) * 256 + rem * 4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(wbuf + (n & 1) * WGB + cb * 16), 16, 0, 0);
         }
     };
 
-    f32x4 acc[2][CT];
+    f32x4 acc[2][TT];
     float* Y = a.Y + (long)b * a.y_bs;
     const float* R = a.R ? a.R + (long)b * a.r_bs : nullptr;
 
     for (int ci = 0; ci < my_chunks; ++ci) {
-        const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * CT;
+        const int mt0 = ((int)blockIdx.y + ci * (int)gridDim.y) * TT;
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int c = 0; c < CT; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < TT; ++c) acc[p][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_s_barrier();                                        // previous pass: every LDS reader is done
         issue_raw(0);
         issue_w(mt0, 0);
@@ -143,20 +149,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16x3_kernel(ConvF16Args a) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                    // image complete; raw buffer free
-            // the next requests, oldest first: tap group 3 s + 1, then the raw planes of the next stage
-            issue_w(mt0, 3 * s + 1);
+            // the next requests, oldest first: the stage's second weight group, then the raw planes of the next stage
+            issue_w(mt0, NG * s + 1);
             if (s + 1 < S) issue_raw(s + 1);
 #pragma unroll
-            for (int tg = 0; tg < 3; ++tg) {
-                const int n = 3 * s + tg;
-                if (tg == 1) {
+            for (int gi = 0; gi < NG; ++gi) {
+                const int n = NG * s + gi, tg = gi % 3, chn = gi / 3;
+                if (gi == 1) {
                     if (s + 1 < S) cf_wait_vmcnt<CF_NRAW>(); else cf_wait_vmcnt<0>();      // group n landed (raw may be in flight)
                     __builtin_amdgcn_s_barrier();                                          // everybody is done with group n - 1
                     issue_w(mt0, n + 1);
-                } else if (tg == 2) {
+                } else if (gi > 1) {
                     cf_wait_vmcnt<0>();
                     __builtin_amdgcn_s_barrier();
-                    if (s + 1 < S) issue_w(mt0, n + 1);
+                    if (gi + 1 < NG || s + 1 < S) issue_w(mt0, n + 1);
                 }
                 const char* wb = wbuf + (n & 1) * WGB;
 #pragma unroll
@@ -175,9 +181,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16x3_kernel(ConvF16Args a) {
                         const cf_h8 wl = *reinterpret_cast<const cf_h8*>(wb + ((c * 3 + tl) * 2 + 1) * 1024 + lane * 16);
 #pragma unroll
                         for (int p = 0; p < 2; ++p) {
-                            acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[p], wh, acc[p][c], 0, 0, 0);
-                            acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p], wl, acc[p][c], 0, 0, 0);
-                            acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p], wh, acc[p][c], 0, 0, 0);
+                            f32x4& t = acc[p][chn * CT + c];
+                            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[p], wh, t, 0, 0, 0);
+                            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p], wl, t, 0, 0, 0);
+                            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p], wh, t, 0, 0, 0);
                         }
                     }
                 }
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16x3_kernel(ConvF16Args a) {
         }
         // ---- epilogue (as conv3x3_ring_kernel)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
+        for (int c = 0; c < TT; ++c) {
             const int co = (mt0 + c) * 16 + r;
             const bool row_ok = mt0 + c < a.mtiles && co < a.Co;
             const float bv = (a.bias && row_ok) ? a.bias[co] : 0.0f;
@@ -232,14 +239,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16x3_kernel(ConvF16Args a) {
     }
 }
 
-template <int CT>
+template <int CT, int NCH = 1>
 static int launch_conv_f16(const ConvF16Args& a, int B, int ygroups, hipStream_t stream) {
     const size_t lds = (size_t)CF_RAWB + CF_IMGB + 2 * (3 * CT * 2048);
     static_assert((size_t)CF_RAWB + CF_IMGB + 2 * (3 * CT * 2048) <= 160 * 1024, "LDS");
-    IRM_ALLOW_BIG_LDS((&conv3x3_f16x3_kernel<CT>));
+    IRM_ALLOW_BIG_LDS((&conv3x3_f16x3_kernel<CT, NCH>));
     const int tiles_y = (a.H + CF_TH - 1) / CF_TH;
     dim3 grid(a.tiles_x * tiles_y, ygroups, B);
-    hipLaunchKernelGGL((conv3x3_f16x3_kernel<CT>), grid, dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv3x3_f16x3_kernel<CT, NCH>), grid, dim3(512), lds, stream, a);
     return irm_launch_status();
 }
 
@@ -262,11 +269,13 @@ extern "C" int irm_conv3x3_f16x3_f32(const float* wp_split, float inv_scale, con
     const int nchunks = (a.mtiles + ct - 1) / (ct > 0 ? ct : 1);
     if (ygroups <= 0) ygroups = 1;
     if (ygroups > nchunks) ygroups = nchunks;
-    switch (ct) {
+    switch (ct) {                     // output tiles per pass: 1 ... 4 (one weight chunk), 8 / 12 (2 / 3 chunks of 4)
         case 1: return launch_conv_f16<1>(a, B, ygroups, stream);
         case 2: return launch_conv_f16<2>(a, B, ygroups, stream);
         case 3: return launch_conv_f16<3>(a, B, ygroups, stream);
         case 4: return launch_conv_f16<4>(a, B, ygroups, stream);
+        case 8: return launch_conv_f16<4, 2>(a, B, ygroups, stream);
+        case 12: return launch_conv_f16<4, 3>(a, B, ygroups, stream);
         default: return IRM_EINVAL;
     }
 }

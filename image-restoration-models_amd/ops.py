@@ -421,12 +421,18 @@ def conv3x3(wp, x, y, ci: int, co: int, *, bias=None, relu1=False, res=None, res
     if isinstance(wp, tuple):
         wps, inv_scale = wp
         if ct is None:
-            ct = 4 if mt % 4 == 0 or mt > 9 else 3 if mt % 3 == 0 or mt > 4 else min(mt, 4)
+            # output tiles per pass: 12 / 8 = 3 / 2 weight chunks of 4 per fetched + converted input tile (Co >= 128: the
+            # up-sampling convs), else one chunk of <= 4
+            ct = 12 if mt >= 12 else 8 if mt >= 8 else 4 if mt % 4 == 0 else 3 if mt % 3 == 0 or mt > 4 else min(mt, 4)
+            if os.environ.get("IRM_CONV_ONE_CHUNK"):
+                ct = 4 if mt % 4 == 0 or mt > 9 else 3 if mt % 3 == 0 or mt > 4 else min(mt, 4)
             while ct > 1 and blocks * -(-mt // ct) < 256:       # small images: more passes, more workgroups
-                ct -= 1
+                ct = {12: 8, 8: 4}.get(ct, ct - 1)
         if ygroups is None:
             nchunks = -(-mt // ct)
             ygroups = max(1, min(nchunks, -(-512 // blocks)))
+            while nchunks % ygroups:                            # equal numbers of passes per workgroup
+                ygroups += 1
         _launch("conv3x3_f16x3", 18.0 * B * ci * co * H * W, nbytes, "irm_conv3x3_f16x3_f32", _hip.ptr(wps), float(inv_scale),
                 _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y), _hip.ptr(res), _bs(res), _hip.ptr(bias), B, ci, co, H, W,
                 int(relu1), int(res_mode), int(relu2), int(store_mode), ct, ygroups,

@@ -650,6 +650,10 @@ CONV_F16_CASES = [
     (64, 1, 12, 20, 1, True, False, 2, False, 0, None),        # DnCNN last layer: x - conv
     (128, 128, 8, 8, 2, True, False, 1, True, 0, 4),           # REDNet-style: conv + skip + relu
     (70, 50, 20, 44, 1, True, False, 0, False, 0, 2),          # ragged channel counts
+    (96, 192, 16, 64, 2, False, False, 0, False, 2, 12),       # up: all 12 output tiles in ONE pass (3 weight chunks of 4)
+    (64, 384, 8, 32, 1, True, False, 0, False, 2, 12),         # 24 output tiles: two passes of 12
+    (40, 150, 16, 36, 1, True, True, 0, False, 0, 8),          # 10 output tiles: a pass of 8 + a ragged pass, ragged channels
+    (192, 384, 8, 32, 2, False, False, 0, False, 2, None),     # the launch plan's own choice (ct 12)
 ]
 
 
