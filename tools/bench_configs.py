@@ -21,7 +21,7 @@ from irm_amd import deblurganv2, dncnn, mair, ops, rednet, restormer, synth, uti
 from irm_amd.configs import PATCH_CONFIG  # noqa: E402
 
 PEAK_TF, PEAK_GBS, PEAK_F16_TF = 157.3, 8000.0, 2500.0
-EMULATED_KERNELS = ("conv3x3_f16x3", "gdfn_fused", "qkv_dw_fused", "gemm1x1_f16x3", "dwgemm_f16x3", "gemm_ps_f16x3", "gemm_ps_res_f16x3")
+EMULATED_KERNELS = ("conv3x3_f16x3", "attn_gdfn_fused", "gdfn_fused", "qkv_dw_fused", "gemm1x1_f16x3", "dwgemm_f16x3", "gemm_ps_f16x3", "gemm_ps_res_f16x3")
 MFMA_KERNELS = {"gemm1x1", "conv3x3", "dwgemm", "mdta_gram"}
 
 
