@@ -27,6 +27,8 @@ SIGNATURES = {
     "irm_gemm1x1_f16x3_f32": [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P],
     "irm_ln_split_f16": [_P, _L, _P, _P, _I, _F, _F, _P, _I, _I, _I, _P],
     "irm_ln_gemm_presplit_f16x3_f32": [_P, _P, _L, _P, _P, _I, _F, _F, _P, _L, _P, _F, _I, _I, _I, _I, _I, _P],
+    "irm_ln_gemm_presplit_cl_f16x3_f32": [_P, _P, _L, _P, _P, _I, _F, _F, _P, _L, _P, _F, _I, _I, _I, _I, _I, _I, _P],
+    "irm_gdfn_tail_f16x3_f32": [_P, _L, _P, _P, _P, _P, _L, _F, _I, _I, _I, _I, _I, _I, _P],
     "irm_gemm_presplit_f16x3_f32": [_P, _P, _P, _L, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "irm_dwconv3x3_gate_split_f16": [_P, _L, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
     "irm_gemm_presplit_res_f16x3_f32": [_P, _P, _P, _L, _P, _L, _P, _F, _I, _I, _I, _I, _I, _P],
@@ -470,6 +472,52 @@ def pack_gdfn_fused(pin_w, pin_b, dw_w, dw_b, pout_w, lnw, lnb, gate_prescale: b
     w2pk = torch.stack([arr2(h2), arr2(l2)], dim=2).contiguous()           # [SS][CT][2][g][m][8]
     w2pk = w2pk.view(-1).view(torch.float32)
     return rec.view(-1).to(dev), w2pk.to(dev), 1.0 / (16.0 * s1), 16.0 / s2
+
+
+def pack_pin_padded(pin_w, pin_b, hid_pad: int):
+    """FeedForward.project_in for the tail path of the C = 192 level: the two halves of its 2 hid output channels moved to
+    [0, hid) and [hid_pad, hid_pad + hid) of 2 hid_pad rows (the rest zero), so that both halves start 16-byte aligned in the
+    channel-last h of irm_ln_gemm_presplit_cl_f16x3_f32.  Returns (fragments, s_w, bias [2 hid_pad] or None)."""
+    w = pin_w.detach().reshape(pin_w.shape[0], -1).float()
+    hid = w.shape[0] // 2
+    assert hid_pad >= hid and hid_pad % 16 == 0
+    wp = torch.zeros(2 * hid_pad, w.shape[1], dtype=torch.float32, device=w.device)
+    wp[:hid] = w[:hid]
+    wp[hid_pad:hid_pad + hid] = w[hid:]
+    frag, s_w = pack_gemm_weight_presplit(wp)
+    bp = None
+    if pin_b is not None:
+        bp = torch.zeros(2 * hid_pad, dtype=torch.float32, device=w.device)
+        bp[:hid] = pin_b.detach().float()[:hid]
+        bp[hid_pad:hid_pad + hid] = pin_b.detach().float()[hid:]
+    return frag, s_w, bp
+
+
+def pack_gdfn_tail(dw_w, dw_b, pout_w):
+    """Operands of irm_gdfn_tail_f16x3_f32 (include/irm_hip.h) from FeedForward.dwconv / project_out (restormer.py:84-93):
+    (rec [S][512], w2, inv_s2); the taps / bias of the multiplier half x 2^-4, project_out as in pack_gdfn_fused."""
+    dev = pout_w.device
+    pout = pout_w.detach().reshape(pout_w.shape[0], -1).double().cpu()
+    C, hid = pout.shape
+    S, CT = (hid + 15) // 16, (C + 15) // 16
+    SS = (S + 1) // 2
+    dwf = torch.zeros(2, 16 * S, 10, dtype=torch.float32)
+    dwf[:, :hid, :9] = dw_w.detach().reshape(2 * hid, 9).float().cpu().view(2, hid, 9)
+    if dw_b is not None:
+        dwf[:, :hid, 9] = dw_b.detach().float().cpu().view(2, hid)
+    dwf[1] *= 0.0625
+    coef = dwf.view(2, S, 16, 10).permute(1, 3, 0, 2).contiguous().view(S, 320)     # [S][t][half * 16 + m]
+    rec = torch.zeros(S, 512, dtype=torch.float32)
+    rec[:, :320] = coef
+    s2 = _pow2_scale(pout)
+    w2f = torch.zeros(16 * CT, 32 * SS, dtype=torch.float32)
+    w2f[:C, :hid] = pout.float() * s2
+    h2, l2 = _split_h(w2f)
+
+    def arr2(t):      # [CT][16 m][SS][2 jh][4 g][4 jl] -> [SS][CT][g][m][jh][jl]
+        return t.view(CT, 16, SS, 2, 4, 4).permute(2, 0, 4, 1, 3, 5)
+    w2pk = torch.stack([arr2(h2), arr2(l2)], dim=2).contiguous().view(-1).view(torch.float32)
+    return rec.view(-1).to(dev), w2pk.to(dev), 16.0 / s2
 
 
 def pack_mfold_frag(m: torch.Tensor) -> torch.Tensor:

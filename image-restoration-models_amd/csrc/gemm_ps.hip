@@ -151,6 +151,7 @@ struct PsArgs {
     const float* lnw; const float* lnb;
     int ln_mode; float eps, x_scale;
     int dbg;                       // IRM_PS_DBG (-DIRM_PROBES builds, timing only): 1 = stores to the dump page, 2 = no MFMAs, 4 = no weight DMA
+    int H, W;                      // YCL kernels: the image is H x W (N = H W), whole 8 x 32 tiles
 };
 
 __device__ float4 ps_dump[256 * 64];
@@ -177,7 +178,10 @@ __device__ __forceinline__ void ps_wait_vmcnt() {
 // LNF: the wave normalises and splits its own pixel tiles while loading them (ps_ln_pixel, the routine of ln_split_kernel)
 // instead of reading fragments: no ln_split launch, no write + read of xs.  Pays where every workgroup does it once
 // (one round, mgroups 1: the K 192 shapes).
-template <int KS, int WP, int CT, int CG, int NW, bool LNF = false>
+// YCL (round 3): y tile-major channel-last [8 x 32 tile][pixel][M] (M % 16 == 0; irm_hip.h) for the GDFN tail kernel
+// (fused_tail.hip): the MFMA operands are swapped (weights = A), so lane (pixel r, g) ends up with channels 4 g .. 4 g + 3 of
+// an output tile - one 16-byte store per tile and pixel; the store count per wave and chunk (the vmcnt arithmetic) is unchanged.
+template <int KS, int WP, int CT, int CG, int NW, bool LNF = false, bool YCL = false>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_ps_kernel(PsArgs a) {
     IRM_KERNEL_ENTRY();
     constexpr int NS = 4;                          // ring depth
@@ -226,6 +230,11 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_ps_kernel(PsArgs a) {
         pt_idx[p] = min(pt, a.npt - 1);
         const int bi = pt_idx[p] / ptl;
         ybase[p] = pt < a.npt ? a.y + (long)bi * a.y_bs + (pt_idx[p] - bi * ptl) * 16 + g * 4 : nullptr;
+        if constexpr (YCL) {
+            const int n = (pt_idx[p] - bi * ptl) * 16 + r, yy = n / a.W, xx = n - yy * a.W;
+            const long px = ((long)((yy >> 3) * (a.W >> 5) + (xx >> 5)) << 8) + ((yy & 7) << 5) + (xx & 31);
+            ybase[p] = pt < a.npt ? a.y + (long)bi * a.y_bs + px * a.M + g * 4 : nullptr;
+        }
     }
     const int nchunks = (a.mtiles + CT - 1) / CT;
     const int c0 = mgi * a.cpg;
@@ -358,22 +367,40 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_ps_kernel(PsArgs a) {
                 for (int cc = 0; cc < CG; ++cc)
 #pragma unroll
                     for (int p = 0; p < WP; ++p)
-                        acc[p][jg * CG + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[ks][p], wh[set][cc], acc[p][jg * CG + cc], 0, 0, 0);
+                        acc[p][jg * CG + cc] = YCL ? __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[set][cc], xl[ks][p], acc[p][jg * CG + cc], 0, 0, 0)
+                                                   : __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[ks][p], wh[set][cc], acc[p][jg * CG + cc], 0, 0, 0);
 #pragma unroll
                 for (int cc = 0; cc < CG; ++cc)
 #pragma unroll
                     for (int p = 0; p < WP; ++p)
-                        acc[p][jg * CG + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[ks][p], wl[set][cc], acc[p][jg * CG + cc], 0, 0, 0);
+                        acc[p][jg * CG + cc] = YCL ? __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[set][cc], xh[ks][p], acc[p][jg * CG + cc], 0, 0, 0)
+                                                   : __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[ks][p], wl[set][cc], acc[p][jg * CG + cc], 0, 0, 0);
 #pragma unroll
                 for (int cc = 0; cc < CG; ++cc)
 #pragma unroll
                     for (int p = 0; p < WP; ++p)
-                        acc[p][jg * CG + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[ks][p], wh[set][cc], acc[p][jg * CG + cc], 0, 0, 0);
+                        acc[p][jg * CG + cc] = YCL ? __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[set][cc], xh[ks][p], acc[p][jg * CG + cc], 0, 0, 0)
+                                                   : __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[ks][p], wh[set][cc], acc[p][jg * CG + cc], 0, 0, 0);
             }
         });
         // ---- chunk epilogue: exactly ST store instructions per wave (masked rows go to the dump page)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
+            if constexpr (YCL) {
+                const int cb = (cm(c) * CT + ct) * 16;                       // (M % 16 == 0: whole tiles)
+                const bool okt = cb < a.M && !IRM_DBG(a.dbg, 1);
+                const f32x4 bv4 = *reinterpret_cast<const f32x4*>(lbias + ((cm(c) - c0) * CT + ct) * 16 + 4 * g);
+#pragma unroll
+                for (int p = 0; p < WP; ++p) {
+                    const float4 v = make_float4(fmaf(acc[p][ct][0], a.out_scale, bv4[0]), fmaf(acc[p][ct][1], a.out_scale, bv4[1]),
+                                                 fmaf(acc[p][ct][2], a.out_scale, bv4[2]), fmaf(acc[p][ct][3], a.out_scale, bv4[3]));
+                    float4* dst = (okt && ybase[p]) ? reinterpret_cast<float4*>(ybase[p] + cb)
+                                                    : ps_dump + ((blockIdx.x & 255) * 64 + lane);
+                    *dst = v;
+                    acc[p][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                continue;
+            }
             const int co = (cm(c) * CT + ct) * 16 + r;
             const bool ok = co < a.M && !IRM_DBG(a.dbg, 1);
             const float bv = lbias[((cm(c) - c0) * CT + ct) * 16 + r];
@@ -394,12 +421,12 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_ps_kernel(PsArgs a) {
     ps_wait_vmcnt<0>();                            // no LDS-DMA may be in flight when the workgroup's LDS is released
 }
 
-template <int KS, int WP, int CT, int CG, int NW, bool LNF = false>
+template <int KS, int WP, int CT, int CG, int NW, bool LNF = false, bool YCL = false>
 static int ps_launch(PsArgs a, hipStream_t stream) {
     a.nblk = (a.npt + NW * WP - 1) / (NW * WP);
     const size_t lds = (size_t)4 * 2 * CT * 1024 + (size_t)a.cpg * CT * 64 + (LNF ? (size_t)KS * 256 : 0);
-    IRM_ALLOW_BIG_LDS((&gemm_ps_kernel<KS, WP, CT, CG, NW, LNF>));
-    hipLaunchKernelGGL((gemm_ps_kernel<KS, WP, CT, CG, NW, LNF>), dim3(a.nblk * a.mgroups), dim3(NW * 64), lds, stream, a);
+    IRM_ALLOW_BIG_LDS((&gemm_ps_kernel<KS, WP, CT, CG, NW, LNF, YCL>));
+    hipLaunchKernelGGL((gemm_ps_kernel<KS, WP, CT, CG, NW, LNF, YCL>), dim3(a.nblk * a.mgroups), dim3(NW * 64), lds, stream, a);
     return irm_launch_status();
 }
 
@@ -458,8 +485,30 @@ extern "C" int irm_ln_gemm_presplit_f16x3_f32(const void* wps, const float* x, l
     a.mgroups = mgroups; a.cpg = (nchunks + mgroups - 1) / mgroups;
     if ((long)(mgroups - 1) * a.cpg >= nchunks) return IRM_EINVAL;
     a.out_scale = out_scale; a.dbg = 0;
-    a.x = x; a.x_bs = x_bs; a.lnw = lnw; a.lnb = lnb; a.ln_mode = ln_mode; a.eps = eps; a.x_scale = x_scale;
+    a.x = x; a.x_bs = x_bs; a.lnw = lnw; a.lnb = lnb; a.ln_mode = ln_mode; a.eps = eps; a.x_scale = x_scale; a.H = 0; a.W = 0;
     return ps_launch<6, 3, 4, 2, 4, true>(a, stream);
+}
+
+// The same launch with y written tile-major channel-last [H/8 * W/32 tiles][256 pixels][M] (header): N = H W, H % 8 == 0,
+// W % 32 == 0, M % 16 == 0 - the layout irm_gdfn_tail_f16x3_f32 reads.
+extern "C" int irm_ln_gemm_presplit_cl_f16x3_f32(const void* wps, const float* x, long x_bs, const float* lnw, const float* lnb,
+                                                 int ln_mode, float x_scale, float eps, float* y, long y_bs, const float* bias,
+                                                 float out_scale, int B, int M, int K, int H, int W, int mgroups,
+                                                 hipStream_t stream) {
+    if (!wps || !x || !lnw || !y || B <= 0 || M <= 0 || H <= 0 || W <= 0 || mgroups <= 0 || K != 192) return IRM_EINVAL;
+    if (ln_mode != IRM_LN_WITHBIAS && ln_mode != IRM_LN_BIASFREE) return IRM_EINVAL;
+    if (ln_mode == IRM_LN_WITHBIAS && !lnb) return IRM_EINVAL;
+    if ((H & 7) || (W & 31) || (M & 15) || (y_bs & 3) || !irm_aligned16(y) || !irm_aligned16(wps) || !(x_scale > 0.0f)) return IRM_EINVAL;
+    PsArgs a;
+    a.xs = nullptr; a.wps = reinterpret_cast<const _Float16*>(wps); a.bias = bias;
+    a.y = y; a.y_bs = y_bs; a.M = M; a.N = H * W; a.mtiles = (M + 15) / 16; a.H = H; a.W = W;
+    a.npt = (int)((long)B * a.N / 16); a.nblk = 0;
+    const int nchunks = (a.mtiles + 3) / 4;
+    a.mgroups = mgroups; a.cpg = (nchunks + mgroups - 1) / mgroups;
+    if ((long)(mgroups - 1) * a.cpg >= nchunks) return IRM_EINVAL;
+    a.out_scale = out_scale; a.dbg = 0;
+    a.x = x; a.x_bs = x_bs; a.lnw = lnw; a.lnb = lnb; a.ln_mode = ln_mode; a.eps = eps; a.x_scale = x_scale;
+    return ps_launch<6, 3, 4, 2, 4, true, true>(a, stream);
 }
 
 // ===============================================================================================================

@@ -186,6 +186,37 @@ def ln_gemm_presplit(wps, x, y, M: int, K: int, lnw, lnb, ln_mode: int, x_scale:
     gemm_presplit(wps, xs, y, M, K, out_scale=out_scale, bias=bias, ct=ct, mgroups=mgroups, wg_shape=shape)
 
 
+def can_gdfn_tail(C: int, H: int, W: int) -> bool:
+    """GDFN tail in one kernel (irm_gdfn_tail_f16x3_f32): the C = 192 level on whole 8 x 32 tiles."""
+    return C == 192 and H % 8 == 0 and W % 32 == 0
+
+
+def ln_gemm_presplit_cl(wps, x, h_cl, M: int, K: int, lnw, lnb, ln_mode: int, x_scale: float, *, out_scale: float, bias=None,
+                        eps: float = 1e-5):
+    """h_cl = W LN(x) + bias written tile-major channel-last [tile][256][M] (flat float32 buffer of B * M * H * W elements):
+    irm_ln_gemm_presplit_cl_f16x3_f32, K = 192, M % 16 == 0."""
+    _chk(x, "x")
+    B, _, H, W = x.shape
+    N = H * W
+    assert K == 192 and M % 16 == 0 and H % 8 == 0 and W % 32 == 0 and h_cl.numel() >= B * M * N and h_cl.is_contiguous()
+    _launch("gemm_ps_f16x3", 2.0 * B * M * K * N, 4.0 * B * N * (K + M), "irm_ln_gemm_presplit_cl_f16x3_f32", _hip.ptr(wps),
+            _hip.ptr(x), _bs(x), _hip.ptr(lnw), _hip.ptr(lnb), int(ln_mode), float(x_scale), float(eps), _hip.ptr(h_cl), M * N,
+            _hip.ptr(bias), float(out_scale), B, M, K, H, W, 1, tag=f"M{M} K{K} N{N} B{B} ln-fused cl")
+
+
+def gdfn_tail(pk, h_cl, x, C: int, hid: int, hid_pad: int, *, bias=None):
+    """x += project_out(gelu(dw(h)[:hid]) * dw(h)[hid:]) + bias in one kernel, h_cl from ln_gemm_presplit_cl (2 hid_pad channels
+    per pixel); pk = _hip.pack_gdfn_tail(...)."""
+    _chk(x, "x")
+    B, _, H, W = x.shape
+    N = H * W
+    rec, w2, inv_s2 = pk
+    assert can_gdfn_tail(C, H, W) and x.shape[1] >= C and h_cl.numel() >= B * 2 * hid_pad * N
+    _launch("gdfn_tail", B * N * (36.0 * hid + 2.0 * hid * C), 4.0 * B * N * (2 * hid_pad + 2 * C), "irm_gdfn_tail_f16x3_f32",
+            _hip.ptr(h_cl), 2 * hid_pad * N, _hip.ptr(rec), _hip.ptr(w2), _hip.ptr(bias), _hip.ptr(x), _bs(x), float(inv_s2),
+            B, C, hid, hid_pad, H, W, tag=f"C{C} hid{hid} {H}x{W} B{B}")
+
+
 GATE_SPLIT_SCALE = 0.0625      # 2^-4: gated activations up to ~1e6 stay inside fp16 (as irm_gemm1x1_f16x3_f32 without LN)
 
 

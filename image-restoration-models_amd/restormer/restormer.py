@@ -198,6 +198,14 @@ class Restormer(nn.Module):
                         # GDFN tail on pre-split operands (gemm_ps.hip): project_out fragments, K padded to 32 ceil(hid / 32)
                         frag, s_w = _hip.pack_gemm_weight_presplit(ff.project_out.weight, k_pad=32 * -(-ff.hidden // 32))
                         pk[name]["pout_ps"] = (frag, 1.0 / (s_w * ops.GATE_SPLIT_SCALE))
+                    if m.dim == 192:
+                        # GDFN tail in one kernel (fused_tail.hip): project_in with its halves padded to a multiple of 16
+                        # channels, written tile-major channel-last; taps / project_out packed for irm_gdfn_tail_f16x3_f32
+                        hp = 16 * -(-ff.hidden // 16)
+                        frag, s_w, bp = _hip.pack_pin_padded(ff.project_in.weight, ff.project_in.bias, hp)
+                        s_x = _hip.ln_split_scale(m.norm2.w, m.norm2.b, m.dim, m.norm2.mode == ops.LN_WITHBIAS)
+                        pk[name]["pin_cl"] = (frag, 1.0 / (s_w * s_x), s_x, bp, hp)
+                        pk[name]["tail"] = _hip.pack_gdfn_tail(ff.dwconv.weight, ff.dwconv.bias, ff.project_out.weight)
                     if m.dim in (192, 384):
                         # LayerNorm + qkv / project_in with pre-split operands (gemm_ps.hip): (fragments, 1 / (s_w s_x), s_x);
                         # power-of-two scales on both operands - no range guard needed
@@ -320,6 +328,13 @@ class Restormer(nn.Module):
             ops.gemm1x1(mfold, qkv2[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n,
                         stats_out=stats if fuse else None, split=s_fold)
         # --- feed-forward branch: x += project_out(gelu(dw(h1)) * dw(h2))   (restormer.py:88-93, 148)
+        if (split and "tail" in w and ops.can_gdfn_tail(C, H, W) and not os.environ.get("IRM_NO_GDFN_TAIL")):
+            # LayerNorm + project_in -> h tile-major channel-last; depth-wise + gate + project_out + residual in ONE kernel
+            frag, out_scale, s_x, bp, hp = w["pin_cl"]
+            h_cl = self._buf("h_cl", B * 2 * hp * N, dev)
+            ops.ln_gemm_presplit_cl(frag, x, h_cl, 2 * hp, C, w["n2w"], w["n2b"], blk.norm2.mode, s_x, out_scale=out_scale, bias=bp)
+            ops.gdfn_tail(w["tail"], h_cl, x, C, hid, hp, bias=w["pout_b"])
+            return False
         h = big_a[:B * 2 * hid * N].view(B, 2 * hid, H, W)
         g = big_b[:B * hid * N].view(B, hid, H, W)
         if presplit:

@@ -169,6 +169,50 @@ def test_attn_gdfn_fused_tile_major_layouts(dev, C, hid, H, W, B, lay):
     assert torch.all(yb[:, :2] == 7.0)
 
 
+@pytest.mark.parametrize("H,W,B,ln,bias", [(16, 64, 2, 1, False), (24, 32, 1, 2, True), (8, 96, 3, 1, True), (40, 64, 1, 1, True)])
+def test_gdfn_tail_c192(dev, H, W, B, ln, bias):
+    """C = 192: LayerNorm + project_in with h written tile-major channel-last (irm_ln_gemm_presplit_cl_f16x3_f32), then the
+    depth-wise conv, the gate, project_out and the residual in ONE kernel (irm_gdfn_tail_f16x3_f32), vs float64."""
+    C, hid, hp = 192, 510, 512
+    tag = f"gt{H}_{W}_{B}_{ln}"
+    ws = 0.2
+    big = rnd(tag + "x", (B, C + 3, H, W), -1.5, 2.0)
+    lnw = rnd(tag + "lw", (C,), 0.5, 1.5)
+    lnb = rnd(tag + "lb", (C,), -0.2, 0.2) if ln == 1 else None
+    pin_w, pout_w = rnd(tag + "pi", (2 * hid, C), -ws, ws), rnd(tag + "po", (C, hid), -ws, ws)
+    dw_w = rnd(tag + "dw", (2 * hid, 9), -0.4, 0.4)
+    pin_b = rnd(tag + "pib", (2 * hid,), -0.3, 0.3) if bias else None
+    dw_b = rnd(tag + "dwb", (2 * hid,), -0.3, 0.3) if bias else None
+    pout_b = rnd(tag + "pob", (C,), -0.3, 0.3) if bias else None
+    x = big[:, 1:1 + C]
+    ref = gdfn_ref(x, lnw, lnb, ln, pin_w, pin_b, dw_w, dw_b, pout_w, pout_b)
+    frag, s_w, bp = _hip.pack_pin_padded(pin_w.to(dev), None if pin_b is None else pin_b.to(dev), hp)
+    s_x = _hip.ln_split_scale(lnw, lnb, C, ln == 1)
+    pk = _hip.pack_gdfn_tail(dw_w, dw_b, pout_w.to(dev))
+    xb = big.to(dev)
+    h_cl = torch.full((B * 2 * hp * H * W + 64,), 7.0, device=dev)
+    ops.ln_gemm_presplit_cl(frag, xb[:, 1:1 + C], h_cl, 2 * hp, C, lnw.to(dev), None if lnb is None else lnb.to(dev), ln, s_x,
+                            out_scale=1.0 / (s_w * s_x), bias=bp)
+    assert torch.all(h_cl[-64:] == 7.0), "wrote past h"
+    # h itself: un-permute [B][tile][256][2 hp] and compare with float64 project_in(LN(x))
+    xd = x.double()
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    xn = ((xd - mu) if ln == 1 else xd) / torch.sqrt(var + 1e-5) * lnw.double()[None, :, None, None]
+    if ln == 1:
+        xn = xn + lnb.double()[None, :, None, None]
+    href = F.conv2d(xn, pin_w.double()[:, :, None, None], None if pin_b is None else pin_b.double())
+    hc = h_cl[:-64].cpu().view(B, H // 8, W // 32, 8, 32, 2 * hp).permute(0, 5, 1, 3, 2, 4).reshape(B, 2 * hp, H, W)
+    assert float((hc[:, :hid].double() - href[:, :hid]).abs().max()) <= TOL * max(1.0, float(href.abs().max()))
+    assert float((hc[:, hp:hp + hid].double() - href[:, hid:]).abs().max()) <= TOL * max(1.0, float(href.abs().max()))
+    assert float(hc[:, hid:hp].abs().max()) == 0.0 and float(hc[:, hp + hid:].abs().max()) == 0.0
+    ops.gdfn_tail(pk, h_cl, xb[:, 1:1 + C], C, hid, hp, bias=None if pout_b is None else pout_b.to(dev))
+    y = xb.cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((y[:, 1:1 + C].double() - ref).abs().max())
+    assert err <= TOL * scale, (err, scale)
+    assert torch.equal(y[:, 0], big[:, 0]) and torch.equal(y[:, 1 + C:], big[:, 1 + C:]), "wrote outside its channel slice"
+
+
 def test_gdfn_fused_deterministic(dev):
     C, hid, H, W = 96, 255, 32, 64
     x = rnd("detx", (2, C, H, W), -2, 2).to(dev)
