@@ -189,6 +189,8 @@ ROOFLINE_KERNELS = {
                    r"^lnpw_dw_fused_kernel<\d+, \d+, true, false"),
     "qkv_dw_fused": ("lnpw_dw_fused_kernel<!GATE> (irm_qkv_dw_fused[_tm]_f16x3_f32: LayerNorm + qkv 1x1 + depth-wise 3x3)", "hbm",
                      r"^lnpw_dw_fused_kernel<\d+, \d+, false"),
+    "gdfn_tail": ("gdfn_tail_kernel (irm_gdfn_tail_f16x3_f32: depth-wise 3x3 + GELU gate + project_out + residual of the C = 192 level in "
+                  "one kernel on a tile-major channel-last h)", "hbm", r"^gdfn_tail_kernel"),
     "gemm1x1_f16x3": ("gemm_xres_kernel / gemm_ring_kernel<F16> (irm_gemm1x1_f16x3_f32: LayerNorm + 1x1 conv, fp32 emulated "
                       "by three fp16 MFMAs, fp32 accumulate)", "hbm", r"^(gemm_ring_kernel<.*, true>|gemm_xres_kernel)"),
     "gemm_ps_f16x3": ("gemm_ps_kernel (irm_gemm_presplit_f16x3_f32: 1x1 conv on pre-split fp16 hi/lo fragments of LayerNorm(x), "
@@ -365,7 +367,7 @@ def main():
             dom = max(ks, key=lambda k: ks[k]["ms"])
             g = ks[dom]
             label, bound, pmc_re = ROOFLINE_KERNELS.get(dom, (dom, "hbm", None))
-            emulated = dom in ("attn_gdfn_fused", "gdfn_fused", "qkv_dw_fused", "gemm1x1_f16x3", "dwgemm_f16x3", "gemm_ps_f16x3")
+            emulated = dom in ("attn_gdfn_fused", "gdfn_tail", "gdfn_fused", "qkv_dw_fused", "gemm1x1_f16x3", "dwgemm_f16x3", "gemm_ps_f16x3")
             if bound == "mfma" and emulated:
                 # the unit that executes the arithmetic is the fp16 matrix core: three MFMA passes per fp32 product
                 ach, peak, unit = 3.0 * g["flops"] / (g["ms"] * 1e-3) / 1e12, PEAK_F16_MFMA_TFLOPS, "TFLOP/s"
