@@ -4,7 +4,8 @@
 //                                                                       block's residual, restormer.py:84-93, 148)
 //
 // with h = project_in(LN(x)) written by irm_ln_gemm_presplit_cl_f16x3_f32 tile-major channel-last, its two halves padded to
-// HP channels each ([tile][256 pixels][2 HP]).  Before: a gated depth-wise kernel wrote g (hid planes) and a streaming GEMM
+// HP channels each, in chunks of 64 channels ([tile][2 HP / 64][256 pixels][64]: the producer's chunk of 64 channels is one
+// contiguous run per pixel tile).  Before: a gated depth-wise kernel wrote g (hid planes) and a streaming GEMM
 // read it back - 1.2 GB per 12-tile block at C = 192 - as two launches; here g never leaves the CU.
 //
 // This is the second half of the GDFN branch kernel of the C <= 96 levels (fused_block.hip) with the h image filled from
@@ -32,7 +33,7 @@ typedef unsigned ft_u4 __attribute__((ext_vector_type(4)));
 __device__ __attribute__((aligned(16))) float ft_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
 struct TailArgs {
-    const float* Hh; long h_bs;           // [B][tiles][256][CB]
+    const float* Hh; long h_bs;           // [B][tiles][CB / 64][256][64]
     float* X; long x_bs;                  // [B][C][H][W], updated in place
     const float* rec;                     // [S][512]: depth-wise taps [10][32] of stage s (9 taps + bias; second half x 2^-4), pad
     const float* w2;                      // [ceil(S/2)][CT][hi|lo][64 lanes][8 halves], as irm_gdfn_fused_f16x3_f32
@@ -146,7 +147,9 @@ __global__ __launch_bounds__(512, 2) void gdfn_tail_kernel(TailArgs a) {
             const int hr = px / FT_HC, hc = px - hr * FT_HC;
             const int gy = ty0 - 1 + hr, gx = tx0 - 1 + hc;
             const bool valid = px < FT_NP, inside = valid && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            goff[k] = inside ? (((gy >> 3) * a.tiles_x + (gx >> 5)) * 256 + (gy & 7) * FT_TW + (gx & 31)) * a.CB + (pc & 3) * 4 + (pc >> 2) * a.HP
+            // h: [tile][CB / 64 chunks][256 pixels][64 channels]; the multiplier half starts HP / 64 chunks further on
+            goff[k] = inside ? ((gy >> 3) * a.tiles_x + (gx >> 5)) * 256 * a.CB + ((gy & 7) * FT_TW + (gx & 31)) * 64 + (pc & 3) * 4 +
+                               (pc >> 2) * (a.HP / 64) * (256 * 64)
                              : -1;
             loff[k] = (unsigned)(PL_OFF + ((valid ? px : FT_NP + (tid & 15)) * FT_PS) * 4 + (pc & 3) * 16 + (pc >> 2) * 64);
         }
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void gdfn_tail_kernel(TailArgs a) {
         auto load_h = [&](int s) {
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
-                const float* src = goff[k] >= 0 ? Hh + goff[k] + 16 * s : ft_zero_page;
+                const float* src = goff[k] >= 0 ? Hh + goff[k] + (s >> 2) * (256 * 64) + (s & 3) * 16 : ft_zero_page;
                 hreg[k] = *reinterpret_cast<const f32x4*>(src);
             }
         };
@@ -334,7 +337,7 @@ extern "C" int irm_gdfn_tail_f16x3_f32(const float* h_cl, long h_bs, const float
                                        float* x, long x_bs, float inv_s2, int B, int C, int hid, int hid_pad, int H, int W,
                                        hipStream_t stream) {
     if (!h_cl || !rec || !w2 || !x || B <= 0 || C <= 0 || hid <= 0 || H <= 0 || W <= 0) return IRM_EINVAL;
-    if (C != 192 || (H & 7) || (W & 31) || hid_pad < hid || (hid_pad & 15)) return IRM_EINVAL;
+    if (C != 192 || (H & 7) || (W & 31) || hid_pad < hid || (hid_pad & 63)) return IRM_EINVAL;
     if ((h_bs & 3) || (x_bs & 3) || !irm_aligned16(h_cl) || !irm_aligned16(x) || !irm_aligned16(rec) || !irm_aligned16(w2)) return IRM_EINVAL;
     if ((long)(H / 8) * (W / 32) * 256 * 2 * hid_pad >= (1L << 31)) return IRM_EINVAL;       // 32-bit piece offsets
     TailArgs a;

@@ -178,7 +178,7 @@ __device__ __forceinline__ void ps_wait_vmcnt() {
 // LNF: the wave normalises and splits its own pixel tiles while loading them (ps_ln_pixel, the routine of ln_split_kernel)
 // instead of reading fragments: no ln_split launch, no write + read of xs.  Pays where every workgroup does it once
 // (one round, mgroups 1: the K 192 shapes).
-// YCL (round 3): y tile-major channel-last [8 x 32 tile][pixel][M] (M % 16 == 0; irm_hip.h) for the GDFN tail kernel
+// YCL (round 3): y tile-major channel-last in chunks of 64 channels [8 x 32 tile][M / 64][pixel][64] (M % 64 == 0; irm_hip.h) for the GDFN tail kernel
 // (fused_tail.hip): the MFMA operands are swapped (weights = A), so lane (pixel r, g) ends up with channels 4 g .. 4 g + 3 of
 // an output tile - one 16-byte store per tile and pixel; the store count per wave and chunk (the vmcnt arithmetic) is unchanged.
 template <int KS, int WP, int CT, int CG, int NW, bool LNF = false, bool YCL = false>
@@ -232,8 +232,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_ps_kernel(PsArgs a) {
         ybase[p] = pt < a.npt ? a.y + (long)bi * a.y_bs + (pt_idx[p] - bi * ptl) * 16 + g * 4 : nullptr;
         if constexpr (YCL) {
             const int n = (pt_idx[p] - bi * ptl) * 16 + r, yy = n / a.W, xx = n - yy * a.W;
-            const long px = ((long)((yy >> 3) * (a.W >> 5) + (xx >> 5)) << 8) + ((yy & 7) << 5) + (xx & 31);
-            ybase[p] = pt < a.npt ? a.y + (long)bi * a.y_bs + px * a.M + g * 4 : nullptr;
+            // [tile][64-channel chunk][256 pixels][64 channels]: a workgroup's chunk of CT = 4 tiles is ONE contiguous run
+            // of 256 bytes per pixel x its consecutive pixels (16 KiB per pixel tile), not 256-byte pieces 4 KiB apart
+            const long tl = (long)((yy >> 3) * (a.W >> 5) + (xx >> 5)), pin = ((yy & 7) << 5) + (xx & 31);
+            ybase[p] = pt < a.npt ? a.y + (long)bi * a.y_bs + tl * 256 * a.M + pin * 64 + g * 4 : nullptr;
         }
     }
     const int nchunks = (a.mtiles + CT - 1) / CT;
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_ps_kernel(PsArgs a) {
                 for (int p = 0; p < WP; ++p) {
                     const float4 v = make_float4(fmaf(acc[p][ct][0], a.out_scale, bv4[0]), fmaf(acc[p][ct][1], a.out_scale, bv4[1]),
                                                  fmaf(acc[p][ct][2], a.out_scale, bv4[2]), fmaf(acc[p][ct][3], a.out_scale, bv4[3]));
-                    float4* dst = (okt && ybase[p]) ? reinterpret_cast<float4*>(ybase[p] + cb)
+                    float4* dst = (okt && ybase[p]) ? reinterpret_cast<float4*>(ybase[p] + (long)(cb >> 6) * (256 * 64) + (cb & 63))
                                                     : ps_dump + ((blockIdx.x & 255) * 64 + lane);
                     *dst = v;
                     acc[p][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -489,8 +491,8 @@ extern "C" int irm_ln_gemm_presplit_f16x3_f32(const void* wps, const float* x, l
     return ps_launch<6, 3, 4, 2, 4, true>(a, stream);
 }
 
-// The same launch with y written tile-major channel-last [H/8 * W/32 tiles][256 pixels][M] (header): N = H W, H % 8 == 0,
-// W % 32 == 0, M % 16 == 0 - the layout irm_gdfn_tail_f16x3_f32 reads.
+// The same launch with y written tile-major channel-last in chunks of 64 channels [H/8 * W/32 tiles][M / 64][256 pixels][64]
+// (header): N = H W, H % 8 == 0, W % 32 == 0, M % 64 == 0 - the layout irm_gdfn_tail_f16x3_f32 reads.
 extern "C" int irm_ln_gemm_presplit_cl_f16x3_f32(const void* wps, const float* x, long x_bs, const float* lnw, const float* lnb,
                                                  int ln_mode, float x_scale, float eps, float* y, long y_bs, const float* bias,
                                                  float out_scale, int B, int M, int K, int H, int W, int mgroups,
@@ -498,7 +500,7 @@ extern "C" int irm_ln_gemm_presplit_cl_f16x3_f32(const void* wps, const float* x
     if (!wps || !x || !lnw || !y || B <= 0 || M <= 0 || H <= 0 || W <= 0 || mgroups <= 0 || K != 192) return IRM_EINVAL;
     if (ln_mode != IRM_LN_WITHBIAS && ln_mode != IRM_LN_BIASFREE) return IRM_EINVAL;
     if (ln_mode == IRM_LN_WITHBIAS && !lnb) return IRM_EINVAL;
-    if ((H & 7) || (W & 31) || (M & 15) || (y_bs & 3) || !irm_aligned16(y) || !irm_aligned16(wps) || !(x_scale > 0.0f)) return IRM_EINVAL;
+    if ((H & 7) || (W & 31) || (M & 63) || (y_bs & 3) || !irm_aligned16(y) || !irm_aligned16(wps) || !(x_scale > 0.0f)) return IRM_EINVAL;
     PsArgs a;
     a.xs = nullptr; a.wps = reinterpret_cast<const _Float16*>(wps); a.bias = bias;
     a.y = y; a.y_bs = y_bs; a.M = M; a.N = H * W; a.mtiles = (M + 15) / 16; a.H = H; a.W = W;

@@ -193,12 +193,12 @@ def can_gdfn_tail(C: int, H: int, W: int) -> bool:
 
 def ln_gemm_presplit_cl(wps, x, h_cl, M: int, K: int, lnw, lnb, ln_mode: int, x_scale: float, *, out_scale: float, bias=None,
                         eps: float = 1e-5):
-    """h_cl = W LN(x) + bias written tile-major channel-last [tile][256][M] (flat float32 buffer of B * M * H * W elements):
-    irm_ln_gemm_presplit_cl_f16x3_f32, K = 192, M % 16 == 0."""
+    """h_cl = W LN(x) + bias written tile-major channel-last in 64-channel chunks [tile][M / 64][256][64] (flat float32 buffer
+    of B * M * H * W elements): irm_ln_gemm_presplit_cl_f16x3_f32, K = 192, M % 64 == 0."""
     _chk(x, "x")
     B, _, H, W = x.shape
     N = H * W
-    assert K == 192 and M % 16 == 0 and H % 8 == 0 and W % 32 == 0 and h_cl.numel() >= B * M * N and h_cl.is_contiguous()
+    assert K == 192 and M % 64 == 0 and H % 8 == 0 and W % 32 == 0 and h_cl.numel() >= B * M * N and h_cl.is_contiguous()
     _launch("gemm_ps_f16x3", 2.0 * B * M * K * N, 4.0 * B * N * (K + M), "irm_ln_gemm_presplit_cl_f16x3_f32", _hip.ptr(wps),
             _hip.ptr(x), _bs(x), _hip.ptr(lnw), _hip.ptr(lnb), int(ln_mode), float(x_scale), float(eps), _hip.ptr(h_cl), M * N,
             _hip.ptr(bias), float(out_scale), B, M, K, H, W, 1, tag=f"M{M} K{K} N{N} B{B} ln-fused cl")

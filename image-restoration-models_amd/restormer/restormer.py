@@ -201,7 +201,7 @@ class Restormer(nn.Module):
                     if m.dim == 192:
                         # GDFN tail in one kernel (fused_tail.hip): project_in with its halves padded to a multiple of 16
                         # channels, written tile-major channel-last; taps / project_out packed for irm_gdfn_tail_f16x3_f32
-                        hp = 16 * -(-ff.hidden // 16)
+                        hp = 64 * -(-ff.hidden // 64)
                         frag, s_w, bp = _hip.pack_pin_padded(ff.project_in.weight, ff.project_in.bias, hp)
                         s_x = _hip.ln_split_scale(m.norm2.w, m.norm2.b, m.dim, m.norm2.mode == ops.LN_WITHBIAS)
                         pk[name]["pin_cl"] = (frag, 1.0 / (s_w * s_x), s_x, bp, hp)

@@ -114,8 +114,9 @@ int irm_gemm1x1_f16x3_f32(const float* wp_split, long w_bs, const float* x, long
 int irm_ln_gemm_presplit_f16x3_f32(const void* wps, const float* x, long x_bs, const float* lnw, const float* lnb, int ln_mode,
                                    float x_scale, float eps, float* y, long y_bs, const float* bias, float out_scale, int B,
                                    int M, int K, int N, int mgroups, irm_stream_t stream);
-/* The same launch with y tile-major channel-last [H/8 * W/32 tiles][256 pixels][M] (N = H W; H % 8 == 0, W % 32 == 0,
- * M % 16 == 0): the MFMA operands are swapped so that a lane holds 4 channels of its pixel - 16-byte channel-last stores. */
+/* The same launch with y tile-major channel-last in chunks of 64 channels [H/8 * W/32 tiles][M / 64][256 pixels][64] (N = H W;
+ * H % 8 == 0, W % 32 == 0, M % 64 == 0): the MFMA operands are swapped so that a lane holds 4 channels of its pixel (16-byte
+ * stores), and the 64 channels a workgroup produces at a time form one contiguous run over its consecutive pixels. */
 int irm_ln_gemm_presplit_cl_f16x3_f32(const void* wps, const float* x, long x_bs, const float* lnw, const float* lnb, int ln_mode,
                                    float x_scale, float eps, float* y, long y_bs, const float* bias, float out_scale, int B,
                                    int M, int K, int H, int W, int mgroups, irm_stream_t stream);
@@ -239,11 +240,12 @@ int irm_attn_gdfn_fused_f16x3_f32(const float* rec, const float* w2, const float
 /* GDFN tail of the C = 192 level in one kernel (round 3, fused_tail.hip):
  *   x += project_out(gelu_erf(dw(h)[:hid]) * dw(h)[hid:]) + bias2      (restormer.py:84-93, 148), in place on x [B][C][H][W]
  * h_cl: h = project_in(LN(x)) + b as irm_ln_gemm_presplit_cl_f16x3_f32 writes it - tile-major channel-last
- *   [H/8 * W/32 tiles][256 pixels][2 hid_pad], the two halves of h (gate | multiplier) at channels [0, hid) and
- *   [hid_pad, hid_pad + hid), the rest zero (project_in packed with padded halves: _hip.pack_pin_padded);
+ *   in chunks of 64 channels, [H/8 * W/32 tiles][2 hid_pad / 64][256 pixels][64], the two halves of h (gate | multiplier)
+ *   at channels [0, hid) and [hid_pad, hid_pad + hid), the rest zero (project_in packed with padded halves:
+ *   _hip.pack_pin_padded);
  * rec [S = ceil(hid/16)][512] floats: [10][32] = the 9 depth-wise taps + bias of the stage's channels (16 gate | 16 multiplier;
  *   the multiplier's taps and bias x 2^-4), pad;  w2, inv_s2 as for irm_gdfn_fused_f16x3_f32 with CT = 12
- *   (Python: _hip.pack_gdfn_tail).  C == 192, H % 8 == 0, W % 32 == 0, hid_pad % 16 == 0.
+ *   (Python: _hip.pack_gdfn_tail).  C == 192, H % 8 == 0, W % 32 == 0, hid_pad % 64 == 0.
  * Replaces irm_dwconv3x3_gate_f32 + irm_gemm1x1_f16x3_f32(res = x): the gated tensor never reaches HBM. */
 int irm_gdfn_tail_f16x3_f32(const float* h_cl, long h_bs, const float* rec, const float* w2, const float* bias2, float* x,
                             long x_bs, float inv_s2, int B, int C, int hid, int hid_pad, int H, int W, irm_stream_t stream);

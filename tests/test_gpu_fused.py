@@ -194,14 +194,15 @@ def test_gdfn_tail_c192(dev, H, W, B, ln, bias):
     ops.ln_gemm_presplit_cl(frag, xb[:, 1:1 + C], h_cl, 2 * hp, C, lnw.to(dev), None if lnb is None else lnb.to(dev), ln, s_x,
                             out_scale=1.0 / (s_w * s_x), bias=bp)
     assert torch.all(h_cl[-64:] == 7.0), "wrote past h"
-    # h itself: un-permute [B][tile][256][2 hp] and compare with float64 project_in(LN(x))
+    # h itself: un-permute [B][tile][chunk of 64 channels][256][64] and compare with float64 project_in(LN(x))
     xd = x.double()
     mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
     xn = ((xd - mu) if ln == 1 else xd) / torch.sqrt(var + 1e-5) * lnw.double()[None, :, None, None]
     if ln == 1:
         xn = xn + lnb.double()[None, :, None, None]
     href = F.conv2d(xn, pin_w.double()[:, :, None, None], None if pin_b is None else pin_b.double())
-    hc = h_cl[:-64].cpu().view(B, H // 8, W // 32, 8, 32, 2 * hp).permute(0, 5, 1, 3, 2, 4).reshape(B, 2 * hp, H, W)
+    hc = (h_cl[:-64].cpu().view(B, H // 8, W // 32, 2 * hp // 64, 8, 32, 64).permute(0, 3, 6, 1, 4, 2, 5)
+          .reshape(B, 2 * hp, H, W))                     # [B][ty][tx][chunk][8][32][64] -> planar
     assert float((hc[:, :hid].double() - href[:, :hid]).abs().max()) <= TOL * max(1.0, float(href.abs().max()))
     assert float((hc[:, hp:hp + hid].double() - href[:, hid:]).abs().max()) <= TOL * max(1.0, float(href.abs().max()))
     assert float(hc[:, hid:hp].abs().max()) == 0.0 and float(hc[:, hp + hid:].abs().max()) == 0.0
