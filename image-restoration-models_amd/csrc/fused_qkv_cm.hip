@@ -1,0 +1,344 @@
+// The front half of MDTA for the C <= 96 levels with a CHANNEL-MAJOR hidden image (round 3, late):
+//
+//   q, k, v = dw3x3(W LN(x) + b)       (norm1 + Attention.qkv + qkv_dwconv, restormer.py:25-70, 105-106, 116)
+//
+// Same work items, operands and fp32 emulation as lnpw_dw_fused_kernel<!GATE> (fused_block.hip): an 8 x 32 tile with its
+// 1-pixel halo, the normalised input split once into fp16 hi/lo and resident in registers, stages of 32 output channels.
+// What differs is the layout of the 32-channel h image between the 1x1 conv and the depth-wise stencil.  The steady
+// iteration of the branch kernels is a SUM of matrix, vector and LDS time, and with the PIXEL on the
+// lane 44 of the 64 ds_read_b128 per wave and stage are the stencil's: every lane reads its 3 columns x 4 rows although its
+// neighbours read two of the same columns, plus 20 broadcast reads of the taps.  Here
+//   * the 1x1 conv runs with the pixels as the MFMA ROW index (the resident input is the A operand, the weights B): a lane
+//     receives 4 consecutive pixels of ONE hidden channel and parks them with one ds_write_b128 in a channel-major image
+//     [32 channels][10 rows x 36 pixel slots];
+//   * the stencil has the CHANNEL on the lane: wave w owns output row w, lane (i, g) channel i of a 16-channel tile and the
+//     8 pixels 8 g .. 8 g + 7: per halo row two ds_read_b128 and one ds_read_b64 give its 10-pixel segment (9 reads per tile
+//     instead of 24 + taps 20), the 9 taps + bias of its channel are 10 scalars;
+//   * the 8 results of a lane are 8 consecutive pixels of one channel: q, k go to their tile-major [tile][2C][256] block with
+//     TWO 16-byte stores (before: 16 four-byte stores per stage), v to its channel-last block.
+// Channel rows sit 1728 bytes apart plus 16 o(i) bytes, o = 0,1,4,5,8,9,12,13 for the rows {0-3, 12-15} and again for {4-11}
+// of a 16-channel tile: the (non-contiguous) 16-lane groups of ds_read_b128 - rows {0-3, 12-15} at pixel group g with rows
+// {4-11} at g + 1 - then touch 16 different bank quads.
+// Whole tiles only (H % 8 == 0, W % 32 == 0), C % 16 == 0, M = 3 C; q, k tile-major, v channel-last or planar.
+#include "irm_common.h"
+#include <utility>
+
+typedef _Float16 qc_h8 __attribute__((ext_vector_type(8)));
+typedef float qc_v2 __attribute__((ext_vector_type(2)));
+
+#define QC_TH 8
+#define QC_TW 32
+#define QC_PITCH 36                              // pixel slots per halo row (34 used)
+#define QC_SLOTS ((QC_TH + 2) * QC_PITCH)        // 360
+#define QC_PT 23                                 // 16-slot MFMA tiles (368 slots)
+#define QC_CS 1728                               // bytes between channel rows
+#define QC_IMG (32 * QC_CS)                      // bytes per image
+
+struct QcArgs {
+    const float* X; long x_bs;
+    float* Y; long y_bs;                         // [B][3C][H][W]: q, k tile-major inside [0, 2C), v inside [2C, 3C)
+    const float* rec;                            // records of irm_qkv_dw_fused_f16x3_f32 (include/irm_hip.h)
+    int C, H, W, S, M;
+    int ln_mode; float eps, inv_s1;
+    int x_tm, v_tm;
+    int tiles_x, tiles, items, gpx;
+};
+
+typedef __attribute__((address_space(3))) char qc_lc;
+__device__ __forceinline__ unsigned qc_opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+template <typename T>
+__device__ __forceinline__ T qc_ld(const qc_lc* base, unsigned voff, int imm) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) T*>(base + voff + imm);
+}
+template <typename T>
+__device__ __forceinline__ void qc_st(qc_lc* base, unsigned voff, int imm, T v) {
+    *reinterpret_cast<__attribute__((address_space(3))) T*>(base + voff + imm) = v;
+}
+template <int NP>
+__device__ __forceinline__ void qc_dma(const float* src, float* dst, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < (NP + 7) / 8; ++i) {
+        const int pc = wave + 8 * i;
+        if (pc < NP)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(dst + pc * 256), 16, 0, 0);
+    }
+}
+// byte offset of channel row c (0 .. 31) inside an image
+__device__ __forceinline__ unsigned qc_row(int c) {
+    const int i = c & 15;
+    const int rk = i < 4 ? i : i < 12 ? i - 4 : i - 8;                 // rank inside {0-3, 12-15} or inside {4-11}
+    const int o = (rk >> 1) * 4 + (rk & 1);                            // 0, 1, 4, 5, 8, 9, 12, 13
+    // the row's bank-quad phase is (c CS / 16 + o) mod 16; CS / 16 = 108 = 12 (mod 16): take that out so that the phase is o
+    const int fix = (16 - ((c * (QC_CS / 16)) & 15)) & 15;
+    return (unsigned)(c * QC_CS + 16 * ((o + fix) & 15));
+}
+
+template <int KS>
+__global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
+    IRM_KERNEL_ENTRY();
+    constexpr int W1F = KS * 1024, RECF = W1F + 512, RECP = KS * 4 + 2;
+    constexpr int SLOT_B = RECF * 4, CF_OFF = W1F * 4;
+    constexpr int OSC_OFF = 2 * SLOT_B, MSK_OFF = OSC_OFF + 368 * 4, PL_OFF = MSK_OFF + 368 * 4;
+    static_assert(PL_OFF % 16 == 0 && PL_OFF + 2 * QC_IMG <= 160 * 1024, "LDS");
+    static_assert(15 * 16 + 368 * 4 <= QC_CS, "row + phase shift inside the row stride");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    qc_lc* lds = (qc_lc*)smem;
+    float* slots = smem;
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const long plane = (long)a.H * a.W;
+    const int S = a.S;
+    const int per = (a.items + 7) >> 3;
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    auto item_of = [&](int round) { const int i = round * a.gpx + pos; return i < per ? xcd * per + i : a.items; };
+
+    int round = 0;
+    int item = item_of(0);
+    if (item >= a.items) return;
+
+    for (;;) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, g = lane >> 4, r = lane & 15;
+        const int b = item / a.tiles, tile = item - b * a.tiles;
+        const int ty0 = (tile / a.tiles_x) * QC_TH, tx0 = (tile % a.tiles_x) * QC_TW;
+        const float* X = a.X + (long)b * a.x_bs;
+        float* Y = a.Y + (long)b * a.y_bs;
+        const int nitem = item_of(round + 1);
+        const unsigned vw = qc_opaque((unsigned)(lane * 16));
+
+        // ------------------------------------------------------------ input: lane (r, g) -> pixel slot 16 (wave + 8 j) + r
+        float xr[3][KS][8];
+        bool inside[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int p = 16 * (wave + 8 * j) + r, ph = p / QC_PITCH, pc = p - ph * QC_PITCH;
+            const int gy0 = ty0 - 1 + ph, gx0 = tx0 - 1 + pc;
+            inside[j] = p < QC_SLOTS && pc < QC_TW + 2 && gy0 >= 0 && gy0 < a.H && gx0 >= 0 && gx0 < a.W;
+            const int gy = min(max(gy0, 0), a.H - 1), gx = min(max(gx0, 0), a.W - 1);
+            if (a.x_tm) {
+                const float* xp = X + (unsigned)((((gy >> 3) * a.tiles_x + (gx >> 5)) * 256 + (gy & 7) * QC_TW + (gx & 31)) * a.C);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int c0 = 32 * ks + 8 * min(g, max((a.C - 32 * ks - 8) / 8, 0));
+                    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(xp + c0), hi4 = *reinterpret_cast<const f32x4*>(xp + c0 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { xr[j][ks][e] = lo4[e]; xr[j][ks][4 + e] = hi4[e]; }
+                }
+            } else {
+                const unsigned pix = (unsigned)(gy * a.W + gx);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const unsigned off = pix + (unsigned)(8 * min(g, max((a.C - 32 * ks - 8) / 8, 0)) * plane);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xr[j][ks][e] = (X + (long)(32 * ks + e) * plane)[off];
+                }
+            }
+        }
+        // the previous item's last barrier has passed: every LDS region is free
+        qc_dma<RECP>(a.rec, slots + RECF, wave, lane);                  // record 0 (prologue GEMM) -> slot 1
+        qc_dma<RECP>(a.rec + RECF, slots, wave, lane);                  // record 1 (iteration 0)   -> slot 0
+
+        // ------------------------------------------------------------ LayerNorm + fp16 split (as fused_block.hip)
+        qc_h8 xh[3][KS], xl[3][KS];
+        // (FULL: C == 32 KS, no channel masks - the same expressions as lnpw_dw_fused_kernel's specialised copies, so that the
+        // compiler contracts the same multiply-adds and the two kernels stay bit-identical)
+        auto ln_phase = [&](auto FULL_, auto WBK_) {
+            constexpr bool FULL = decltype(FULL_)::value;
+            constexpr int WBK = decltype(WBK_)::value;
+            const float invC = 1.0f / (float)a.C;
+            const bool wb = WBK < 0 ? a.ln_mode == IRM_LN_WITHBIAS : WBK == 1;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float v[KS][8];
+                float s = 0.f;
+                int kl[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) { kl[ks] = FULL ? 8 : a.C - 32 * ks - 8 * g; if (!FULL) asm volatile("" : "+v"(kl[ks])); }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { v[ks][e] = xr[j][ks][e]; s += (FULL || e < kl[ks]) ? v[ks][e] : 0.f; }
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                const float mean = s * invC;
+                float q = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float d = v[ks][e] - mean;
+                        q += (FULL || e < kl[ks]) ? d * d : 0.f;
+                        v[ks][e] = (FULL || e < kl[ks]) ? (wb ? d : v[ks][e]) : 0.f;
+                    }
+                q += __shfl_xor(q, 16);
+                q += __shfl_xor(q, 32);
+                const float var = q * invC;
+                const float ms = wb ? var : fmaf(mean, mean, var);
+                const float rs = ms > 0.f ? 16.0f / sqrtf(ms) : 0.f;
+                const float oscj = a.inv_s1 * sqrtf(ms / (var + a.eps));
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        unsigned hh, ll;
+                        irm_split2(__fmul_rn(v[ks][e], rs), __fmul_rn(v[ks][e + 1], rs), hh, ll);
+                        reinterpret_cast<unsigned*>(&xh[j][ks])[e / 2] = hh;
+                        reinterpret_cast<unsigned*>(&xl[j][ks])[e / 2] = ll;
+                    }
+                // per-pixel factors of the accumulators (h = acc osc + bias msk; zero outside the image: the reference
+                // zero-pads h) for the lanes that will hold this pixel's h values: through LDS
+                if (g == 0 && wave + 8 * j < QC_PT) {
+                    const int p = 16 * (wave + 8 * j) + r;
+                    qc_st<float>(lds, (unsigned)(OSC_OFF + p * 4), 0, inside[j] ? oscj : 0.f);
+                    qc_st<float>(lds, (unsigned)(MSK_OFF + p * 4), 0, inside[j] ? 1.f : 0.f);
+                }
+            }
+        };
+        {
+            const std::true_type T_; const std::false_type F_;
+            if (a.C == 32 * KS) {
+                if (a.ln_mode == IRM_LN_WITHBIAS) ln_phase(T_, std::integral_constant<int, 1>{});
+                else ln_phase(T_, std::integral_constant<int, 0>{});
+            } else {
+                ln_phase(F_, std::integral_constant<int, -1>{});
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        f32x4 osc4[3], msk4[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned po = (unsigned)((16 * min(wave + 8 * j, QC_PT - 1) + 4 * g) * 4);
+            osc4[j] = qc_ld<f32x4>(lds, po, OSC_OFF);
+            msk4[j] = qc_ld<f32x4>(lds, po, MSK_OFF);
+        }
+
+        // one stage of the 1x1 conv: 32 channels (2 tiles) for this wave's 3 pixel tiles -> image img
+        const unsigned vrow0 = qc_opaque(qc_row(r)), vrow1 = qc_opaque(qc_row(16 + r));
+        auto gemm1 = [&](int slot, int img) {
+#pragma unroll
+            for (int hct = 0; hct < 2; ++hct) {
+                f32x4 acc[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const qc_h8 bh = qc_ld<qc_h8>(lds, vw, slot * SLOT_B + ((hct * KS + ks) * 2) * 1024);
+                    const qc_h8 bl = qc_ld<qc_h8>(lds, vw, slot * SLOT_B + ((hct * KS + ks) * 2 + 1) * 1024);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        // (the product order of lnpw_dw_fused_kernel: W_lo x_hi, W_hi x_lo, W_hi x_hi - bit-identical sums)
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[j][ks], bl, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[j][ks], bh, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[j][ks], bh, acc[j], 0, 0, 0);
+                    }
+                }
+                const float b1 = qc_ld<float>(lds, (unsigned)(r * 4), slot * SLOT_B + CF_OFF + 320 * 4 + hct * 64);
+                const unsigned vr = hct ? vrow1 : vrow0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (wave + 8 * j < QC_PT) {
+                        f32x4 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = fmaf(acc[j][e], osc4[j][e], b1 * msk4[j][e]);
+                        qc_st<f32x4>(lds, vr + (unsigned)((16 * (wave + 8 * j) + 4 * g) * 4), PL_OFF + img * QC_IMG, h);
+                    }
+                }
+            }
+        };
+        // the stencil of a stage: row `wave`, both channel tiles; results to q, k (tile-major) or v
+        auto stencil = [&](int slot, int img, int st) {
+#pragma unroll
+            for (int hct = 0; hct < 2; ++hct) {
+                const int ch = 32 * st + 16 * hct + r;
+                const unsigned vr = (hct ? vrow1 : vrow0) + (unsigned)((wave * QC_PITCH + 8 * g) * 4);
+                const unsigned vt = (unsigned)((16 * hct + r) * 4);
+                float o[8];
+                const float kb = qc_ld<float>(lds, vt, slot * SLOT_B + CF_OFF + 9 * 128);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = kb;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const f32x4 p0 = qc_ld<f32x4>(lds, vr, PL_OFF + img * QC_IMG + dy * QC_PITCH * 4);
+                    const f32x4 p1 = qc_ld<f32x4>(lds, vr, PL_OFF + img * QC_IMG + dy * QC_PITCH * 4 + 16);
+                    const qc_v2 p2 = qc_ld<qc_v2>(lds, vr, PL_OFF + img * QC_IMG + dy * QC_PITCH * 4 + 32);
+                    const float P[10] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3], p2[0], p2[1]};
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float t = qc_ld<float>(lds, vt, slot * SLOT_B + CF_OFF + (dy * 3 + dx) * 128);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = fmaf(t, P[e + dx], o[e]);
+                    }
+                }
+                if (ch >= a.M) continue;
+                if (ch < 2 * a.C) {
+                    float* yt = Y + (long)tile * (2L * a.C * 256) + ch * 256 + wave * QC_TW + 8 * g;
+                    *reinterpret_cast<f32x4*>(yt) = (f32x4){o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<f32x4*>(yt + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+                } else if (a.v_tm) {
+                    float* yt = Y + 2L * a.C * plane + (long)tile * (a.C * 256L) + (wave * QC_TW + 8 * g) * a.C + (ch - 2 * a.C);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) yt[e * a.C] = o[e];
+                } else {
+                    float* yt = Y + (long)ch * plane + (long)(ty0 + wave) * a.W + tx0 + 8 * g;
+                    *reinterpret_cast<f32x4*>(yt) = (f32x4){o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<f32x4*>(yt + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+                }
+            }
+        };
+
+        gemm1(1, 0);                                                     // stage 0 (record 0 in slot 1) -> image 0
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int it = 0; it < S; ++it) {
+            const int par = it & 1;
+            // record it + 1 sits in slot par: weights of stage it + 1, taps of stage it; record it + 2 -> the other slot
+            if (it + 1 < S) qc_dma<RECP>(a.rec + (long)(it + 2) * RECF, slots + (par ^ 1) * RECF, wave, lane);
+            if (it + 1 < S) gemm1(par, par ^ 1);
+            stencil(par, par, it);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (nitem >= a.items) break;
+        item = nitem;
+        ++round;
+    }
+}
+
+template <int KS>
+static int qc_launch(QcArgs a, int B, hipStream_t stream) {
+    const size_t lds = (size_t)2 * (KS * 1024 + 512) * 4 + 2 * 368 * 4 + 2 * QC_IMG;
+    IRM_ALLOW_BIG_LDS((&qkv_cm_kernel<KS>));
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return IRM_ELAUNCH;
+    a.tiles_x = a.W / QC_TW;
+    a.tiles = a.tiles_x * (a.H / QC_TH);
+    a.items = B * a.tiles;
+    const int per = (a.items + 7) >> 3;
+    a.gpx = (n + 7) / 8;
+    if (a.gpx > per) a.gpx = per;
+    hipLaunchKernelGGL((qkv_cm_kernel<KS>), dim3(a.gpx * 8), dim3(512), lds, stream, a);
+    return irm_launch_status();
+}
+
+// Same contract as irm_qkv_dw_fused_tm_f16x3_f32 (q, k tile-major; v channel-last when v_tm, else planar); header.
+extern "C" int irm_qkv_dw_cm_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode, float eps,
+                                       float inv_s1, int B, int C, int H, int W, int x_tm, int v_tm, hipStream_t stream) {
+    if (!rec || !x || !y || x == y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return IRM_EINVAL;
+    if (C > 96 || (C & 15) || (H & 7) || (W & 31) || (long)3 * C * H * W >= (1L << 30)) return IRM_EINVAL;
+    if (ln_mode != IRM_LN_WITHBIAS && ln_mode != IRM_LN_BIASFREE) return IRM_EINVAL;
+    if ((x_bs & 3) || (y_bs & 3) || !irm_aligned16(x) || !irm_aligned16(y) || !irm_aligned16(rec)) return IRM_EINVAL;
+    QcArgs a;
+    a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.rec = rec; a.C = C; a.H = H; a.W = W; a.M = 3 * C; a.S = (3 * C + 31) / 32;
+    a.ln_mode = ln_mode; a.eps = eps; a.inv_s1 = inv_s1; a.x_tm = x_tm ? 1 : 0; a.v_tm = v_tm ? 1 : 0;
+    a.tiles_x = 0; a.tiles = 0; a.items = 0; a.gpx = 0;
+    switch ((C + 31) / 32) {
+        case 3: return qc_launch<3>(a, B, stream);
+        case 2: return qc_launch<2>(a, B, stream);
+        case 1: return qc_launch<1>(a, B, stream);
+    }
+    return IRM_EINVAL;
+}

@@ -356,7 +356,8 @@ def qkv_dw_fused(pk, x, y, C: int, M: int, *, ln_mode, eps: float = 1e-5, tm: bo
     N = H * W
     if tm:
         assert M == 3 * C and y.shape[1] == M and H % 8 == 0 and W % 32 == 0
-        _launch("qkv_dw_fused", B * N * (2.0 * M * C + 18.0 * M), 4.0 * B * N * (C + M), "irm_qkv_dw_fused_tm_f16x3_f32",
+        _launch("qkv_dw_fused", B * N * (2.0 * M * C + 18.0 * M), 4.0 * B * N * (C + M),
+                "irm_qkv_dw_cm_f16x3_f32" if os.environ.get("IRM_QKV_CM") else "irm_qkv_dw_fused_tm_f16x3_f32",
                 _hip.ptr(rec), _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y), int(ln_mode), float(eps), float(inv_s1), B, C,
                 H, W, int(x_tm), int(v_tm), tag=f"C{C} M{M} {H}x{W} B{B} tm")
         return

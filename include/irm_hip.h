@@ -222,6 +222,12 @@ int irm_qkv_dw_fused_f16x3_f32(const float* rec, const float* x, long x_bs, floa
  * The first kernel of a stage reads planar, the last writes planar. */
 int irm_qkv_dw_fused_tm_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode, float eps,
                                   float inv_s1, int B, int C, int H, int W, int x_tm, int v_tm, irm_stream_t stream);
+/* irm_qkv_dw_cm_f16x3_f32 (round 3, fused_qkv_cm.hip): the same contract as irm_qkv_dw_fused_tm_f16x3_f32 (same `rec`, q, k
+ * tile-major, v channel-last when v_tm else planar, x channel-last when x_tm else planar; bit-identical results) with a
+ * channel-major hidden image: the 1x1 conv with the pixels as the MFMA row index, the stencil with the channel on the lane
+ * (~40 % fewer LDS reads per stage), q, k stored 16 bytes at a time. */
+int irm_qkv_dw_cm_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode, float eps,
+                            float inv_s1, int B, int C, int H, int W, int x_tm, int v_tm, irm_stream_t stream);
 /* irm_attn_gdfn_fused_f16x3_f32 (round 3): the last step of the attention branch inside the GDFN kernel's prologue,
  *   x' = x + bias_o + Mfold[b] v          (restormer.py:131, 147: project_out(attn @ v) + x, Mfold by irm_mdta_finalize_frag_f16x3_f32)
  *   y  = x' + project_out(gelu_erf(dw(h)[:hid]) * dw(h)[hid:]) + bias2,  h = project_in(LN(x')) + b      (:76-93, 148)
