@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
     IRM_KERNEL_ENTRY();
     constexpr int W1F = KS * 1024, RECF = W1F + 512, RECP = KS * 4 + 2;
     constexpr int SLOT_B = RECF * 4, CF_OFF = W1F * 4;
-    constexpr int OSC_OFF = 2 * SLOT_B, MSK_OFF = OSC_OFF + 368 * 4, PL_OFF = MSK_OFF + 368 * 4;
+    constexpr int OSC_OFF = 3 * SLOT_B, MSK_OFF = OSC_OFF + 368 * 4, PL_OFF = MSK_OFF + 368 * 4;   // three record slots
     static_assert(PL_OFF % 16 == 0 && PL_OFF + 2 * QC_IMG <= 160 * 1024, "LDS");
     static_assert(15 * 16 + 368 * 4 <= QC_CS, "row + phase shift inside the row stride");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -96,26 +96,37 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
     int round = 0;
     int item = item_of(0);
     if (item >= a.items) return;
-
+    float xr[3][KS][8];                             // raw input of the item (free again after the LayerNorm phase: the
+                                                    // next item's input is requested into it three iterations before the end)
     for (;;) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, g = lane >> 4, r = lane & 15;
         const int b = item / a.tiles, tile = item - b * a.tiles;
         const int ty0 = (tile / a.tiles_x) * QC_TH, tx0 = (tile % a.tiles_x) * QC_TW;
-        const float* X = a.X + (long)b * a.x_bs;
         float* Y = a.Y + (long)b * a.y_bs;
         const int nitem = item_of(round + 1);
         const unsigned vw = qc_opaque((unsigned)(lane * 16));
 
         // ------------------------------------------------------------ input: lane (r, g) -> pixel slot 16 (wave + 8 j) + r
-        float xr[3][KS][8];
         bool inside[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int p = 16 * (wave + 8 * j) + r, ph = p / QC_PITCH, pc = p - ph * QC_PITCH;
             const int gy0 = ty0 - 1 + ph, gx0 = tx0 - 1 + pc;
             inside[j] = p < QC_SLOTS && pc < QC_TW + 2 && gy0 >= 0 && gy0 < a.H && gx0 >= 0 && gx0 < a.W;
+        }
+        auto load_x = [&](int item) {
+            int t2 = threadIdx.x;
+            asm volatile("" : "+v"(t2));
+            const int r = t2 & 15, g = (t2 & 63) >> 4;
+            const int b = item / a.tiles, tile = item - b * a.tiles;
+            const int ty0 = (tile / a.tiles_x) * QC_TH, tx0 = (tile % a.tiles_x) * QC_TW;
+            const float* X = a.X + (long)b * a.x_bs;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int p = 16 * (wave + 8 * j) + r, ph = p / QC_PITCH, pc = p - ph * QC_PITCH;
+            const int gy0 = ty0 - 1 + ph, gx0 = tx0 - 1 + pc;
             const int gy = min(max(gy0, 0), a.H - 1), gx = min(max(gx0, 0), a.W - 1);
             if (a.x_tm) {
                 const float* xp = X + (unsigned)((((gy >> 3) * a.tiles_x + (gx >> 5)) * 256 + (gy & 7) * QC_TW + (gx & 31)) * a.C);
@@ -136,9 +147,12 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
                 }
             }
         }
-        // the previous item's last barrier has passed: every LDS region is free
-        qc_dma<RECP>(a.rec, slots + RECF, wave, lane);                  // record 0 (prologue GEMM) -> slot 1
-        qc_dma<RECP>(a.rec + RECF, slots, wave, lane);                  // record 1 (iteration 0)   -> slot 0
+        };
+        if (round == 0) load_x(item);
+        // the previous item's last barrier has passed: every LDS region is free.  Record k lives in slot k % 3.
+        qc_dma<RECP>(a.rec, slots, wave, lane);
+        qc_dma<RECP>(a.rec + RECF, slots + RECF, wave, lane);
+        if (S >= 2) qc_dma<RECP>(a.rec + 2 * RECF, slots + 2 * RECF, wave, lane);
 
         // ------------------------------------------------------------ LayerNorm + fp16 split (as fused_block.hip)
         qc_h8 xh[3][KS], xl[3][KS];
@@ -289,17 +303,27 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
             }
         };
 
-        gemm1(1, 0);                                                     // stage 0 (record 0 in slot 1) -> image 0
+        gemm1(0, 0);                                                     // stage 0 (record 0) -> image 0
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        // iteration it: the 1x1 conv of stage it + 1 (weights: record it + 1) into image (it + 1) & 1, the stencil of stage it
+        // (taps: record it + 1) from image it & 1; record it + 3 is requested into the slot record it left.  The LAST request
+        // (record S) goes out in iteration S - 3: behind it the wave's vector-memory queue holds nothing it has to wait for
+        // any more, so the next item's input is requested right there and stays in flight for the last ~2.5 iterations
+        // (the pixel-on-lane kernel can request it only in its last iteration: it has no registers free before).
+        const int it_pf = max(S - 3, 0);
+        int s1 = 1, s3 = 0;                                              // slots of record it + 1 / it + 3
         for (int it = 0; it < S; ++it) {
-            const int par = it & 1;
-            // record it + 1 sits in slot par: weights of stage it + 1, taps of stage it; record it + 2 -> the other slot
-            if (it + 1 < S) qc_dma<RECP>(a.rec + (long)(it + 2) * RECF, slots + (par ^ 1) * RECF, wave, lane);
-            if (it + 1 < S) gemm1(par, par ^ 1);
-            stencil(par, par, it);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const bool dma = it + 3 <= S;
+            if (dma) qc_dma<RECP>(a.rec + (long)(it + 3) * RECF, slots + s3 * RECF, wave, lane);
+            if (it + 1 < S) gemm1(s1, (it + 1) & 1);
+            stencil(s1, it & 1, it);
+            if (it <= it_pf) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (the stage's stores included)
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (it == it_pf) { load_x(min(nitem, a.items - 1)); __builtin_amdgcn_sched_barrier(0); }
             __builtin_amdgcn_s_barrier();
+            s1 = s1 == 2 ? 0 : s1 + 1;
+            s3 = s3 == 2 ? 0 : s3 + 1;
         }
         if (nitem >= a.items) break;
         item = nitem;
@@ -309,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
 
 template <int KS>
 static int qc_launch(QcArgs a, int B, hipStream_t stream) {
-    const size_t lds = (size_t)2 * (KS * 1024 + 512) * 4 + 2 * 368 * 4 + 2 * QC_IMG;
+    const size_t lds = (size_t)3 * (KS * 1024 + 512) * 4 + 2 * 368 * 4 + 2 * QC_IMG;
     IRM_ALLOW_BIG_LDS((&qkv_cm_kernel<KS>));
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
