@@ -148,7 +148,12 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
             }
         }
         };
-        if (round == 0) load_x(item);
+        // KS == 3 (C = 96): the 72 input registers of the next item do not fit beside the stencil's read-ahead (40 registers):
+        // measured, the read-ahead is worth more (C 96, 12 x 512^2 in isolation: 1.52 ms with it, 1.60 with the early request
+        // instead, 2.25 with both and 155 spilled registers; two thirds of the request early: 1.87) - the input is requested
+        // at the start of the item there
+        constexpr bool PREFETCH = KS <= 2;
+        if (!PREFETCH || round == 0) load_x(item);
         // the previous item's last barrier has passed: every LDS region is free.  Record k lives in slot k % 3.
         qc_dma<RECP>(a.rec, slots, wave, lane);
         qc_dma<RECP>(a.rec + RECF, slots + RECF, wave, lane);
@@ -231,9 +236,8 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
 
         // one stage of the 1x1 conv: 32 channels (2 tiles) for this wave's 3 pixel tiles -> image img
         const unsigned vrow0 = qc_opaque(qc_row(r)), vrow1 = qc_opaque(qc_row(16 + r));
-        auto gemm1 = [&](int slot, int img) {
-#pragma unroll
-            for (int hct = 0; hct < 2; ++hct) {
+        auto gemm1h = [&](int slot, int img, int hct) {
+            {
                 f32x4 acc[3];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -262,31 +266,43 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
                 }
             }
         };
+        auto gemm1 = [&](int slot, int img) { gemm1h(slot, img, 0); gemm1h(slot, img, 1); };
         // the stencil of a stage: row `wave`, both channel tiles; results to q, k (tile-major) or v
-        auto stencil = [&](int slot, int img, int st) {
+        // the reads of one (16-channel tile, row) unit: issued BEFORE the 1x1 conv of the same channel tile of the next stage, so
+        // that their LDS latency passes under its MFMAs; used by the FMAs behind it
+        f32x4 sp0[3], sp1[3];
+        qc_v2 sp2[3];
+        float stap[10];
+        auto st_read = [&](int slot, int img, int hct) {
+            const unsigned vr = (hct ? vrow1 : vrow0) + (unsigned)((wave * QC_PITCH + 8 * g) * 4);
+            const unsigned vt = (unsigned)((16 * hct + r) * 4);
 #pragma unroll
-            for (int hct = 0; hct < 2; ++hct) {
+            for (int dy = 0; dy < 3; ++dy) {
+                sp0[dy] = qc_ld<f32x4>(lds, vr, PL_OFF + img * QC_IMG + dy * QC_PITCH * 4);
+                sp1[dy] = qc_ld<f32x4>(lds, vr, PL_OFF + img * QC_IMG + dy * QC_PITCH * 4 + 16);
+                sp2[dy] = qc_ld<qc_v2>(lds, vr, PL_OFF + img * QC_IMG + dy * QC_PITCH * 4 + 32);
+            }
+#pragma unroll
+            for (int t = 0; t < 10; ++t) stap[t] = qc_ld<float>(lds, vt, slot * SLOT_B + CF_OFF + t * 128);
+        };
+        auto st_comp = [&](int st, int hct) {
+            {
                 const int ch = 32 * st + 16 * hct + r;
-                const unsigned vr = (hct ? vrow1 : vrow0) + (unsigned)((wave * QC_PITCH + 8 * g) * 4);
-                const unsigned vt = (unsigned)((16 * hct + r) * 4);
                 float o[8];
-                const float kb = qc_ld<float>(lds, vt, slot * SLOT_B + CF_OFF + 9 * 128);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = kb;
+                for (int e = 0; e < 8; ++e) o[e] = stap[9];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
-                    const f32x4 p0 = qc_ld<f32x4>(lds, vr, PL_OFF + img * QC_IMG + dy * QC_PITCH * 4);
-                    const f32x4 p1 = qc_ld<f32x4>(lds, vr, PL_OFF + img * QC_IMG + dy * QC_PITCH * 4 + 16);
-                    const qc_v2 p2 = qc_ld<qc_v2>(lds, vr, PL_OFF + img * QC_IMG + dy * QC_PITCH * 4 + 32);
-                    const float P[10] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3], p2[0], p2[1]};
+                    const float P[10] = {sp0[dy][0], sp0[dy][1], sp0[dy][2], sp0[dy][3], sp1[dy][0], sp1[dy][1], sp1[dy][2], sp1[dy][3],
+                                         sp2[dy][0], sp2[dy][1]};
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
-                        const float t = qc_ld<float>(lds, vt, slot * SLOT_B + CF_OFF + (dy * 3 + dx) * 128);
+                        const float t = stap[dy * 3 + dx];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = fmaf(t, P[e + dx], o[e]);
                     }
                 }
-                if (ch >= a.M) continue;
+                if (ch >= a.M) return;
                 if (ch < 2 * a.C) {
                     float* yt = Y + (long)tile * (2L * a.C * 256) + ch * 256 + wave * QC_TW + 8 * g;
                     *reinterpret_cast<f32x4*>(yt) = (f32x4){o[0], o[1], o[2], o[3]};
@@ -316,11 +332,16 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
         for (int it = 0; it < S; ++it) {
             const bool dma = it + 3 <= S;
             if (dma) qc_dma<RECP>(a.rec + (long)(it + 3) * RECF, slots + s3 * RECF, wave, lane);
-            if (it + 1 < S) gemm1(s1, (it + 1) & 1);
-            stencil(s1, it & 1, it);
+            if (it + 1 < S) {
+                st_read(s1, it & 1, 0); gemm1h(s1, (it + 1) & 1, 0); st_comp(it, 0);
+                st_read(s1, it & 1, 1); gemm1h(s1, (it + 1) & 1, 1); st_comp(it, 1);
+            } else {
+                st_read(s1, it & 1, 0); st_comp(it, 0);
+                st_read(s1, it & 1, 1); st_comp(it, 1);
+            }
             if (it <= it_pf) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (the stage's stores included)
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (it == it_pf) { load_x(min(nitem, a.items - 1)); __builtin_amdgcn_sched_barrier(0); }
+            if (PREFETCH && it == it_pf) { load_x(min(nitem, a.items - 1)); __builtin_amdgcn_sched_barrier(0); }
             __builtin_amdgcn_s_barrier();
             s1 = s1 == 2 ? 0 : s1 + 1;
             s3 = s3 == 2 ? 0 : s3 + 1;
