@@ -152,8 +152,10 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
         // measured, the read-ahead is worth more (C 96, 12 x 512^2 in isolation: 1.52 ms with it, 1.60 with the early request
         // instead, 2.25 with both and 155 spilled registers; two thirds of the request early: 1.87) - the input is requested
         // at the start of the item there
+        // ... there it goes out behind the LAST 1x1 conv (iteration S - 2), when the operand registers are free, as in the
+        // pixel-on-lane kernel
         constexpr bool PREFETCH = KS <= 2;
-        if (!PREFETCH || round == 0) load_x(item);
+        if (round == 0) load_x(item);
         // the previous item's last barrier has passed: every LDS region is free.  Record k lives in slot k % 3.
         qc_dma<RECP>(a.rec, slots, wave, lane);
         qc_dma<RECP>(a.rec + RECF, slots + RECF, wave, lane);
@@ -329,22 +331,36 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
         // (the pixel-on-lane kernel can request it only in its last iteration: it has no registers free before).
         const int it_pf = max(S - 3, 0);
         int s1 = 1, s3 = 0;                                              // slots of record it + 1 / it + 3
-        for (int it = 0; it < S; ++it) {
+        for (int it = 0; it + 1 < S; ++it) {
             const bool dma = it + 3 <= S;
             if (dma) qc_dma<RECP>(a.rec + (long)(it + 3) * RECF, slots + s3 * RECF, wave, lane);
-            if (it + 1 < S) {
-                st_read(s1, it & 1, 0); gemm1h(s1, (it + 1) & 1, 0); st_comp(it, 0);
-                st_read(s1, it & 1, 1); gemm1h(s1, (it + 1) & 1, 1); st_comp(it, 1);
-            } else {
-                st_read(s1, it & 1, 0); st_comp(it, 0);
-                st_read(s1, it & 1, 1); st_comp(it, 1);
-            }
+#ifdef QC_NO_PIPE
+            gemm1h(s1, (it + 1) & 1, 0); gemm1h(s1, (it + 1) & 1, 1);
+            st_read(s1, it & 1, 0); st_comp(it, 0);
+            st_read(s1, it & 1, 1); st_comp(it, 1);
+#else
+            st_read(s1, it & 1, 0); gemm1h(s1, (it + 1) & 1, 0); st_comp(it, 0);
+            st_read(s1, it & 1, 1); gemm1h(s1, (it + 1) & 1, 1); st_comp(it, 1);
+#endif
             if (it <= it_pf) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (the stage's stores included)
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (PREFETCH && it == it_pf) { load_x(min(nitem, a.items - 1)); __builtin_amdgcn_sched_barrier(0); }
             __builtin_amdgcn_s_barrier();
             s1 = s1 == 2 ? 0 : s1 + 1;
             s3 = s3 == 2 ? 0 : s3 + 1;
+        }
+        {
+            // last iteration (peeled: no 1x1 conv, so the operand registers are dead here and - where the early request did not
+            // fit - take the next item's input, as in the pixel-on-lane kernel)
+            const int it = S - 1;
+            if (!PREFETCH || S < 2) {
+                load_x(min(nitem, a.items - 1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            st_read(s1, it & 1, 0); st_comp(it, 0);
+            st_read(s1, it & 1, 1); st_comp(it, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
         if (nitem >= a.items) break;
         item = nitem;

@@ -27,6 +27,25 @@ class KernelTimer:
         self.records = []          # (kernel, start_event, end_event, flops, bytes)
         self.detail = detail       # key the summary by kernel + shape tag
         self._chain = {}           # stream -> end event of the previous timed launch on it
+        self._done = {}            # totals of the records already folded (their events released)
+        self._since = 0
+
+    def _fold(self, k, e0, e1, fl, by):
+        d = self._done.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        d["launches"] += 1
+        d["ms"] += e0.elapsed_time(e1)
+        d["flops"] += fl
+        d["bytes"] += by
+
+    def drain(self):
+        """Fold the records whose end event has completed (non-blocking query) and release their events: thousands of
+        live timing events per step otherwise pile up in the HIP runtime until the run ends."""
+        n = 0
+        while n < len(self.records) and self.records[n][2].query():
+            self._fold(*self.records[n])
+            n += 1
+        if n:
+            del self.records[:n]
 
     def break_chain(self):
         """Call when work that is not timed here has been enqueued: the next launch records its own start."""
@@ -45,17 +64,17 @@ class KernelTimer:
         e1.record()
         self._chain[sid] = e1
         self.records.append((kernel + (" " + tag if self.detail and tag else ""), e0, e1, float(flops), float(nbytes)))
+        self._since += 1
+        if self._since >= 256 and not os.environ.get("IRM_TIMER_KEEP_EVENTS"):
+            self._since = 0
+            self.drain()
 
     def summary(self):
         torch.cuda.synchronize()
-        out = {}
-        for k, e0, e1, fl, by in self.records:
-            d = out.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
-            d["launches"] += 1
-            d["ms"] += e0.elapsed_time(e1)
-            d["flops"] += fl
-            d["bytes"] += by
-        return out
+        for rec in self.records:
+            self._fold(*rec)
+        self.records = []
+        return {k: dict(v) for k, v in self._done.items()}
 
 
 #: set to a KernelTimer to time launches; None = plain launches
