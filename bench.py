@@ -303,9 +303,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ops.TIMER = timer
-    # no cyclic-GC pass inside the timed region: the timer keeps two event objects per launch alive (thousands per step), and a
-    # full collection over them stops the launching thread for tens of milliseconds - long enough for the GPU's queue to run dry
-    # (seen as sporadic runs with +30 % step time whose kernel times were unchanged; `host_enqueue_ms_per_step` tells them apart)
+    # no cyclic-GC pass inside the timed region (a full collection over the timer's records stops the launching thread for
+    # tens of milliseconds).  NOTE: on some hosts of the pool about every fifth run shows the two largest
+    # launches of the step (the full-resolution qkv kernels: ~10 GB touched per launch) at 3x their duration, whatever their
+    # layout or kernel version, with every other kernel unchanged; isolated, the same launches never did.  Unexplained
+    # (host-dependent interference); `host_enqueue_ms_per_step` rises with it because the queue backs up.
     import gc
     gc.collect()
     gc.disable()
