@@ -364,6 +364,14 @@ def can_qk_tile_major(C: int, heads: int, H: int, W: int) -> bool:
     return C % 16 == 0 and C % heads == 0 and C // heads in (48, 96) and H % 8 == 0 and W % 32 == 0
 
 
+def _use_qkv_cm(C: int) -> bool:
+    """The channel-major qkv kernel (fused_qkv_cm.hip, bit-identical results): default where it is faster in the model - C <= 64
+    (C = 48 at 512^2: 1.71 vs 1.85 ms per 24 tiles; its registers leave room to request the next input three iterations
+    early); at C = 96 it measures 3.12 vs 2.96 ms in the model (1.58 vs 1.66 ms in isolation).  IRM_QKV_CM=1 / 0 forces / forbids it."""
+    e = os.environ.get("IRM_QKV_CM")
+    return e == "1" if e in ("0", "1") else C <= 64
+
+
 def qkv_dw_fused(pk, x, y, C: int, M: int, *, ln_mode, eps: float = 1e-5, tm: bool = False, x_tm: bool = False,
                  v_tm: bool = False):
     """y[:, :M] = dw3x3(W @ LN(x) + b) in one kernel (y is not x); pk = _hip.pack_qkv_fused(...).
@@ -376,7 +384,7 @@ def qkv_dw_fused(pk, x, y, C: int, M: int, *, ln_mode, eps: float = 1e-5, tm: bo
     if tm:
         assert M == 3 * C and y.shape[1] == M and H % 8 == 0 and W % 32 == 0
         _launch("qkv_dw_fused", B * N * (2.0 * M * C + 18.0 * M), 4.0 * B * N * (C + M),
-                "irm_qkv_dw_cm_f16x3_f32" if os.environ.get("IRM_QKV_CM") else "irm_qkv_dw_fused_tm_f16x3_f32",
+                "irm_qkv_dw_cm_f16x3_f32" if _use_qkv_cm(C) else "irm_qkv_dw_fused_tm_f16x3_f32",
                 _hip.ptr(rec), _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y), int(ln_mode), float(eps), float(inv_s1), B, C,
                 H, W, int(x_tm), int(v_tm), tag=f"C{C} M{M} {H}x{W} B{B} tm")
         return
