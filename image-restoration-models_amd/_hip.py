@@ -43,6 +43,7 @@ SIGNATURES = {
     "irm_mdta_finalize_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "irm_mdta_finalize_f16x3_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "irm_qkv_dw_fused_tm_f16x3_f32": [_P, _P, _L, _P, _L, _I, _F, _F, _I, _I, _I, _I, _I, _I, _P],
+    "irm_qkv_gram_cm_f16x3_f32": [_P, _P, _L, _P, _L, _P, _P, _I, _F, _F, _I, _I, _I, _I, _I, _I, _P],
     "irm_qkv_dw_cm_f16x3_f32": [_P, _P, _L, _P, _L, _I, _F, _F, _I, _I, _I, _I, _I, _I, _P],
     "irm_mdta_gram_tm_f16x3_f32": [_P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
     "irm_mdta_gram_tm_f32": [_P, _L, _P, _I, _I, _I, _I, _I, _P],

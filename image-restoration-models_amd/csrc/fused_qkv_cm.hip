@@ -42,7 +42,12 @@ struct QcArgs {
     int ln_mode; float eps, inv_s1;
     int x_tm, v_tm;
     int tiles_x, tiles, items, gpx;
+    // GRAM (C = 48, one head): q, k are not written; per chunk of QC_NCH consecutive tiles of an image the workgroup emits one
+    // partial record of irm_mdta_gram_* (G[48][48], |q|^2[48], |k|^2[48]) into part[(image * tiles / QC_NCH + chunk)]
+    const float* gscale;                         // [2C] power-of-two operand scales of q, k (_hip.gram_scales)
+    float* part;
 };
+#define QC_NCH 4
 
 typedef __attribute__((address_space(3))) char qc_lc;
 __device__ __forceinline__ unsigned qc_opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
@@ -64,6 +69,10 @@ __device__ __forceinline__ void qc_dma(const float* src, float* dst, int wave, i
                                              (__attribute__((address_space(3))) void*)(dst + pc * 256), 16, 0, 0);
     }
 }
+template <class F, int... Is>
+__device__ __forceinline__ void qc_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void qc_for(F&& f) { qc_for_impl(f, std::make_integer_sequence<int, N>{}); }
 // byte offset of channel row c (0 .. 31) inside an image
 __device__ __forceinline__ unsigned qc_row(int c) {
     const int i = c & 15;
@@ -74,9 +83,18 @@ __device__ __forceinline__ unsigned qc_row(int c) {
     return (unsigned)(c * QC_CS + 16 * ((o + fix) & 15));
 }
 
-template <int KS>
+// GRAM (KS == 2, C = 48, one head of 48 channels): the stencil outputs of q and k ARE fragments of the Gram MFMA (channel on the
+// lane, the wave's 32 pixels of row w as the k index), so the wave keeps its three q tiles as fp16 hi/lo operands (24 registers),
+// and every k tile it produces goes - scaled by the channel's power of two, split, never stored - into 3 x 3 MFMAs onto the
+// wave's own 9 accumulator tiles; squared norms on the vector pipe.  The accumulators run over the QC_NCH tiles of a chunk
+// (a fixed set of consecutive tiles of ONE image, whatever the batch: results do not depend on the batch size); at its end
+// the 8 waves' partials meet in LDS in wave order and one record leaves for mdta_reduce / mdta_finalize.  q, k never reach HBM
+// (2/3 of this kernel's stores, all of the Gram pass's reads) - VERDICT r2 item 1, for the level where the registers allow it:
+// 36 accumulator + 24 operand registers here; c = 96 needs 144 + 48 (two heads of 48: 72 + 48) beside 72 of resident input.
+template <int KS, bool GRAM = false>
 __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
     IRM_KERNEL_ENTRY();
+    static_assert(!GRAM || KS == 2, "GRAM: C = 48");
     constexpr int W1F = KS * 1024, RECF = W1F + 512, RECP = KS * 4 + 2;
     constexpr int SLOT_B = RECF * 4, CF_OFF = W1F * 4;
     constexpr int OSC_OFF = 3 * SLOT_B, MSK_OFF = OSC_OFF + 368 * 4, PL_OFF = MSK_OFF + 368 * 4;   // three record slots
@@ -89,15 +107,29 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const long plane = (long)a.H * a.W;
     const int S = a.S;
-    const int per = (a.items + 7) >> 3;
+    const int per = GRAM ? (a.items / QC_NCH + 7) >> 3 : (a.items + 7) >> 3;
     const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
-    auto item_of = [&](int round) { const int i = round * a.gpx + pos; return i < per ? xcd * per + i : a.items; };
+    auto item_of = [&](int round) {
+        if constexpr (GRAM) {       // units of QC_NCH consecutive tiles: a workgroup walks whole chunks (per counts chunks here)
+            const int i = (round / QC_NCH) * a.gpx + pos;
+            return i < per ? (xcd * per + i) * QC_NCH + round % QC_NCH : a.items;
+        }
+        const int i = round * a.gpx + pos; return i < per ? xcd * per + i : a.items;
+    };
 
     int round = 0;
     int item = item_of(0);
     if (item >= a.items) return;
     float xr[3][KS][8];                             // raw input of the item (free again after the LayerNorm phase: the
                                                     // next item's input is requested into it three iterations before the end)
+    f32x4 gacc[GRAM ? 3 : 1][GRAM ? 3 : 1];         // GRAM: [q tile][k tile], over the tiles of the chunk
+    float gnq[3] = {0.f, 0.f, 0.f}, gnk[3] = {0.f, 0.f, 0.f};
+    if constexpr (GRAM) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y) gacc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     for (;;) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
@@ -154,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
         // at the start of the item there
         // ... there it goes out behind the LAST 1x1 conv (iteration S - 2), when the operand registers are free, as in the
         // pixel-on-lane kernel
-        constexpr bool PREFETCH = KS <= 2;
+        constexpr bool PREFETCH = KS <= 2 && !GRAM;
         if (round == 0) load_x(item);
         // the previous item's last barrier has passed: every LDS region is free.  Record k lives in slot k % 3.
         qc_dma<RECP>(a.rec, slots, wave, lane);
@@ -287,8 +319,10 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
 #pragma unroll
             for (int t = 0; t < 10; ++t) stap[t] = qc_ld<float>(lds, vt, slot * SLOT_B + CF_OFF + t * 128);
         };
-        auto st_comp = [&](int st, int hct) {
+        qc_h8 gqh[GRAM ? 3 : 1], gql[GRAM ? 3 : 1];      // GRAM: the wave's q tiles as MFMA operands (this tile's 32 pixels of row w)
+        auto st_comp = [&](int st, int hct, auto UC) {
             {
+                constexpr int U = decltype(UC)::value;             // GRAM: 16-channel tile index 2 st + hct at compile time
                 const int ch = 32 * st + 16 * hct + r;
                 float o[8];
 #pragma unroll
@@ -303,6 +337,30 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = fmaf(t, P[e + dx], o[e]);
                     }
+                }
+                if constexpr (GRAM && U >= 0 && U < 6) {
+                    // q (U < 3) or k tile: scaled by the channel's power of two (exact), squared norm in fp32, fp16 hi/lo split;
+                    // a k tile goes straight into the 3 x 3 MFMAs against the resident q tiles (the product order of
+                    // mdta_gram_f16x3_kernel: q_lo k_hi, q_hi k_lo, q_hi k_hi)
+                    const float sc = a.gscale[16 * U + r];         // (C = 48: the k scales start at index 48 = 16 * 3)
+                    float nn = 0.f, xs[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { nn = fmaf(o[e], o[e], nn); xs[e] = o[e] * sc; }
+                    qc_h8 hi, lo;
+                    irm_split8(xs, hi, lo);
+                    if constexpr (U < 3) {
+                        gnq[U] += nn; gqh[U] = hi; gql[U] = lo;
+                    } else {
+                        gnk[U - 3] += nn;
+#pragma unroll
+                        for (int x = 0; x < 3; ++x) {
+                            f32x4& t = gacc[x][U - 3];
+                            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(gql[x], hi, t, 0, 0, 0);
+                            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(gqh[x], lo, t, 0, 0, 0);
+                            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(gqh[x], hi, t, 0, 0, 0);
+                        }
+                    }
+                    return;
                 }
                 if (ch >= a.M) return;
                 if (ch < 2 * a.C) {
@@ -329,6 +387,29 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
         // (record S) goes out in iteration S - 3: behind it the wave's vector-memory queue holds nothing it has to wait for
         // any more, so the next item's input is requested right there and stays in flight for the last ~2.5 iterations
         // (the pixel-on-lane kernel can request it only in its last iteration: it has no registers free before).
+        constexpr std::integral_constant<int, -1> NOU{};
+        if constexpr (GRAM) {
+            // C = 48: S = 5 stages, unrolled (the role of a unit - q, k or v tile - is a compile-time property here); the next
+            // item's input is requested in the last iteration (the Gram operands and accumulators take the registers the early
+            // request would need)
+            qc_for<5>([&](auto ITC) {
+                constexpr int it = decltype(ITC)::value;
+                constexpr int s1c = (it + 1) % 3, s3c = it % 3;
+                if constexpr (it + 1 < 5) {
+                    if constexpr (it + 3 <= 5) qc_dma<RECP>(a.rec + (long)(it + 3) * RECF, slots + s3c * RECF, wave, lane);
+                    st_read(s1c, it & 1, 0); gemm1h(s1c, (it + 1) & 1, 0); st_comp(it, 0, std::integral_constant<int, 2 * it>{});
+                    st_read(s1c, it & 1, 1); gemm1h(s1c, (it + 1) & 1, 1); st_comp(it, 1, std::integral_constant<int, 2 * it + 1>{});
+                    if constexpr (it + 3 <= 5) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else {
+                    load_x(min(nitem, a.items - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    st_read(s1c, it & 1, 0); st_comp(it, 0, std::integral_constant<int, 8>{});
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+            });
+        } else {
         const int it_pf = max(S - 3, 0);
         int s1 = 1, s3 = 0;                                              // slots of record it + 1 / it + 3
         for (int it = 0; it + 1 < S; ++it) {
@@ -336,11 +417,11 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
             if (dma) qc_dma<RECP>(a.rec + (long)(it + 3) * RECF, slots + s3 * RECF, wave, lane);
 #ifdef QC_NO_PIPE
             gemm1h(s1, (it + 1) & 1, 0); gemm1h(s1, (it + 1) & 1, 1);
-            st_read(s1, it & 1, 0); st_comp(it, 0);
-            st_read(s1, it & 1, 1); st_comp(it, 1);
+            st_read(s1, it & 1, 0); st_comp(it, 0, NOU);
+            st_read(s1, it & 1, 1); st_comp(it, 1, NOU);
 #else
-            st_read(s1, it & 1, 0); gemm1h(s1, (it + 1) & 1, 0); st_comp(it, 0);
-            st_read(s1, it & 1, 1); gemm1h(s1, (it + 1) & 1, 1); st_comp(it, 1);
+            st_read(s1, it & 1, 0); gemm1h(s1, (it + 1) & 1, 0); st_comp(it, 0, NOU);
+            st_read(s1, it & 1, 1); gemm1h(s1, (it + 1) & 1, 1); st_comp(it, 1, NOU);
 #endif
             if (it <= it_pf) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (the stage's stores included)
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -357,10 +438,52 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
                 load_x(min(nitem, a.items - 1));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            st_read(s1, it & 1, 0); st_comp(it, 0);
-            st_read(s1, it & 1, 1); st_comp(it, 1);
+            st_read(s1, it & 1, 0); st_comp(it, 0, NOU);
+            st_read(s1, it & 1, 1); st_comp(it, 1, NOU);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+        }
+        }      // !GRAM
+        if constexpr (GRAM) {
+            if (round % QC_NCH == QC_NCH - 1) {
+                // ---- end of the chunk: the 8 waves' partial records meet in LDS (the image area is free) in wave order
+                constexpr int REC = 48 * 48 + 96;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    gnq[t] += __shfl_xor(gnq[t], 16); gnq[t] += __shfl_xor(gnq[t], 32);
+                    gnk[t] += __shfl_xor(gnk[t], 16); gnk[t] += __shfl_xor(gnk[t], 32);
+                }
+                float* mine = reinterpret_cast<float*>(smem) + PL_OFF / 4 + wave * REC;
+                float isk[3];
+#pragma unroll
+                for (int y = 0; y < 3; ++y) isk[y] = 1.0f / a.gscale[48 + 16 * y + r];
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    const f32x4 sq4 = *reinterpret_cast<const f32x4*>(a.gscale + 16 * x + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float isq = 1.0f / sq4[e];           // (powers of two: exact)
+#pragma unroll
+                        for (int y = 0; y < 3; ++y) mine[(16 * x + 4 * g + e) * 48 + 16 * y + r] = gacc[x][y][e] * (isq * isk[y]);
+                    }
+                    if (g == 0) { mine[48 * 48 + 16 * x + r] = gnq[x]; mine[48 * 48 + 48 + 16 * x + r] = gnk[x]; }
+                }
+                __syncthreads();
+                const float* all = reinterpret_cast<const float*>(smem) + PL_OFF / 4;
+                float* out = a.part + ((long)b * (a.tiles / QC_NCH) + tile / QC_NCH) * REC;
+                for (int e = threadIdx.x; e < REC; e += 512) {
+                    float sum = all[e];
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) sum += all[w * REC + e];
+                    out[e] = sum;
+                }
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    gnq[x] = 0.f; gnk[x] = 0.f;
+#pragma unroll
+                    for (int y = 0; y < 3; ++y) gacc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
         }
         if (nitem >= a.items) break;
         item = nitem;
@@ -368,21 +491,37 @@ __global__ __launch_bounds__(512, 2) void qkv_cm_kernel(QcArgs a) {
     }
 }
 
-template <int KS>
+template <int KS, bool GRAM = false>
 static int qc_launch(QcArgs a, int B, hipStream_t stream) {
     const size_t lds = (size_t)3 * (KS * 1024 + 512) * 4 + 2 * 368 * 4 + 2 * QC_IMG;
-    IRM_ALLOW_BIG_LDS((&qkv_cm_kernel<KS>));
+    IRM_ALLOW_BIG_LDS((&qkv_cm_kernel<KS, GRAM>));
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return IRM_ELAUNCH;
     a.tiles_x = a.W / QC_TW;
     a.tiles = a.tiles_x * (a.H / QC_TH);
     a.items = B * a.tiles;
-    const int per = (a.items + 7) >> 3;
+    const int per = GRAM ? (a.items / QC_NCH + 7) >> 3 : (a.items + 7) >> 3;
     a.gpx = (n + 7) / 8;
     if (a.gpx > per) a.gpx = per;
-    hipLaunchKernelGGL((qkv_cm_kernel<KS>), dim3(a.gpx * 8), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((qkv_cm_kernel<KS, GRAM>), dim3(a.gpx * 8), dim3(512), lds, stream, a);
     return irm_launch_status();
+}
+
+// v = the last C channels of dw3x3(W LN(x) + b) into y's v part, and the Gram partial records of q, k (never written) into
+// part [B][H W / (256 QC_NCH)][48 * 48 + 96]; C == 48 (one head), (H / 8) (W / 32) % QC_NCH == 0 (header).
+extern "C" int irm_qkv_gram_cm_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, const float* gscale,
+                                         float* part, int ln_mode, float eps, float inv_s1, int B, int C, int H, int W, int x_tm,
+                                         int v_tm, hipStream_t stream) {
+    if (!rec || !x || !y || !gscale || !part || x == y || B <= 0 || H <= 0 || W <= 0) return IRM_EINVAL;
+    if (C != 48 || (H & 7) || (W & 31) || ((H / 8) * (W / 32)) % QC_NCH || (long)3 * C * H * W >= (1L << 30)) return IRM_EINVAL;
+    if (ln_mode != IRM_LN_WITHBIAS && ln_mode != IRM_LN_BIASFREE) return IRM_EINVAL;
+    if ((x_bs & 3) || (y_bs & 3) || !irm_aligned16(x) || !irm_aligned16(y) || !irm_aligned16(rec) || !irm_aligned16(gscale)) return IRM_EINVAL;
+    QcArgs a;
+    a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.rec = rec; a.C = C; a.H = H; a.W = W; a.M = 3 * C; a.S = (3 * C + 31) / 32;
+    a.ln_mode = ln_mode; a.eps = eps; a.inv_s1 = inv_s1; a.x_tm = x_tm ? 1 : 0; a.v_tm = v_tm ? 1 : 0;
+    a.tiles_x = 0; a.tiles = 0; a.items = 0; a.gpx = 0; a.gscale = gscale; a.part = part;
+    return qc_launch<2, true>(a, B, stream);
 }
 
 // Same contract as irm_qkv_dw_fused_tm_f16x3_f32 (q, k tile-major; v channel-last when v_tm, else planar); header.
@@ -395,7 +534,7 @@ extern "C" int irm_qkv_dw_cm_f16x3_f32(const float* rec, const float* x, long x_
     QcArgs a;
     a.X = x; a.x_bs = x_bs; a.Y = y; a.y_bs = y_bs; a.rec = rec; a.C = C; a.H = H; a.W = W; a.M = 3 * C; a.S = (3 * C + 31) / 32;
     a.ln_mode = ln_mode; a.eps = eps; a.inv_s1 = inv_s1; a.x_tm = x_tm ? 1 : 0; a.v_tm = v_tm ? 1 : 0;
-    a.tiles_x = 0; a.tiles = 0; a.items = 0; a.gpx = 0;
+    a.tiles_x = 0; a.tiles = 0; a.items = 0; a.gpx = 0; a.gscale = nullptr; a.part = nullptr;
     switch ((C + 31) / 32) {
         case 3: return qc_launch<3>(a, B, stream);
         case 2: return qc_launch<2>(a, B, stream);

@@ -419,8 +419,33 @@ def mdta_plan(B: int, C: int, heads: int, N: int):
     return chunk, -(-N // chunk), rec
 
 
+QKV_GRAM_NCH = 4          # tiles per partial Gram record of the Gram-fused qkv kernel (QC_NCH in fused_qkv_cm.hip)
+
+
+def can_qkv_gram(C: int, heads: int, H: int, W: int) -> bool:
+    """qkv_gram_cm: the Gram partials inside the qkv kernel (q, k never written): C = 48 with one head, whole tiles in
+    chunks of QKV_GRAM_NCH."""
+    return C == 48 and heads == 1 and H % 8 == 0 and W % 32 == 0 and ((H // 8) * (W // 32)) % QKV_GRAM_NCH == 0
+
+
+def qkv_gram_cm(pk, x, y, gram_scale, part, C: int, *, ln_mode, eps: float = 1e-5, x_tm: bool = False, v_tm: bool = False) -> int:
+    """v = y[:, 2C:] (planar or, v_tm, tile-major channel-last) and the Gram partial records of q, k into `part`
+    (irm_qkv_gram_cm_f16x3_f32); returns nchunk, the records per image, for mdta_fold(..., nchunk_ready=nchunk)."""
+    _chk(x, "x"), _chk(y, "y")
+    B, _, H, W = x.shape
+    assert can_qkv_gram(C, 1, H, W) and y.shape[1] == 3 * C and gram_scale.numel() == 2 * C
+    rec, inv_s1 = pk
+    N = H * W
+    nchunk = (H // 8) * (W // 32) // QKV_GRAM_NCH
+    assert part.numel() >= B * nchunk * (C * C + 2 * C)
+    _launch("qkv_dw_fused", B * N * (2.0 * 3 * C * C + 18.0 * 3 * C + 2.0 * C * C), 4.0 * B * N * 2 * C, "irm_qkv_gram_cm_f16x3_f32",
+            _hip.ptr(rec), _hip.ptr(x), _bs(x), _hip.ptr(y), _bs(y), _hip.ptr(gram_scale), _hip.ptr(part), int(ln_mode),
+            float(eps), float(inv_s1), B, C, H, W, int(x_tm), int(v_tm), tag=f"C{C} {H}x{W} B{B} gram")
+    return nchunk
+
+
 def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, attn=None, split: bool = False,
-              gram_scale=None, frag: bool = False, tm: bool = False):
+              gram_scale=None, frag: bool = False, tm: bool = False, nchunk_ready: int | None = None):
     """Gram pass + finalize: mfold[b] <- packed(W_out @ blockdiag(softmax(...))) (restormer.py:115-131);
     split: in the fp16 hi/lo order of the emulated GEMM kernels.  gram_scale (_hip.gram_scales): the Gram pass runs
     as an fp32 emulation on the fp16 matrix cores (c = 48 / 96 channels per head, N % 64 == 0).  frag: mfold as fp16
@@ -429,10 +454,14 @@ def mdta_fold(qkv, part, gsum, temperature, wout, mfold, C: int, heads: int, att
     B, _, H, W = qkv.shape
     N = H * W
     chunk, nchunk, rec = mdta_plan(B, C, heads, N)
+    if nchunk_ready is not None:
+        nchunk = nchunk_ready                      # the partial records are there already (qkv_gram_cm)
     assert part.numel() >= B * heads * nchunk * rec and gsum.numel() >= B * heads * rec
     c = C // heads
     assert not tm or (c in (48, 96) and N % 256 == 0), "tile-major q, k: the LDS-DMA ring passes only"
-    if gram_scale is not None and c in (48, 96) and N % 64 == 0 and not os.environ.get("IRM_GRAM_EXACT"):
+    if nchunk_ready is not None:
+        pass
+    elif gram_scale is not None and c in (48, 96) and N % 64 == 0 and not os.environ.get("IRM_GRAM_EXACT"):
         assert gram_scale.numel() == 2 * C and gram_scale.is_contiguous()
         _launch("mdta_gram_f16x3", 2.0 * B * heads * c * c * N, 8.0 * B * C * N,
                 "irm_mdta_gram_tm_f16x3_f32" if tm else "irm_mdta_gram_f16x3_f32", _hip.ptr(qkv),

@@ -383,9 +383,18 @@ class Restormer(nn.Module):
         fa = "gdfn_fa" in w and not os.environ.get("IRM_NO_APPLY_FUSE")
         assert not (x_tm or y_tm) or (tm and fa), "tile-major x / y: only between the kernels that understand them"
         v_tm = tm and fa and not os.environ.get("IRM_NO_ACT_TM")
-        ops.qkv_dw_fused(w["qkv_f"], x, qkv, C, 3 * C, ln_mode=blk.norm1.mode, tm=tm, x_tm=x_tm, v_tm=v_tm)
+        gram_in_qkv = (tm and "gram_s" in w and ops.can_qkv_gram(C, heads, H, W) and not os.environ.get("IRM_GRAM_EXACT")
+                       and not os.environ.get("IRM_NO_QKV_GRAM"))
         _, nchunk, rec = ops.mdta_plan(B, C, heads, N)
+        nready = None
+        if gram_in_qkv:
+            nchunk = (H // 8) * (W // 32) // ops.QKV_GRAM_NCH
         part = self._buf("gram_part", B * heads * nchunk * rec, dev)
+        if gram_in_qkv:
+            # C = 48, one head: the Gram partials come out of the qkv kernel, q and k are never written
+            nready = ops.qkv_gram_cm(w["qkv_f"], x, qkv, w["gram_s"], part, C, ln_mode=blk.norm1.mode, x_tm=x_tm, v_tm=v_tm)
+        else:
+            ops.qkv_dw_fused(w["qkv_f"], x, qkv, C, 3 * C, ln_mode=blk.norm1.mode, tm=tm, x_tm=x_tm, v_tm=v_tm)
         gsum = self._buf("gram_sum", B * heads * rec, dev)
         mfold_n = ops.mfold_numel(C)
         ws = self._ws
@@ -400,11 +409,13 @@ class Restormer(nn.Module):
             if mfrag is None or mfrag.device != dev:
                 mfrag = torch.zeros(B * ops.mfold_frag_numel(C), dtype=torch.float32, device=dev)
                 ws[("mfold_frag", C, B)] = mfrag
-            ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfrag, C, heads, gram_scale=w.get("gram_s"), frag=True, tm=tm)
+            ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfrag, C, heads, gram_scale=w.get("gram_s"), frag=True, tm=tm,
+                          nchunk_ready=nready)
             ops.attn_gdfn_fused(w["gdfn_fa"], x, qkv[:, 2 * C:], mfrag, alt, C, hid, ln_mode=blk.norm2.mode,
                                 bias_o=w["wout_b"], bias=w["pout_b"], x_tm=x_tm, v_tm=v_tm, y_tm=y_tm)
             return alt
-        ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=s_fold, gram_scale=w.get("gram_s"), tm=tm)
+        ops.mdta_fold(qkv, part, gsum, w["temp"], w["wout"], mfold, C, heads, split=s_fold, gram_scale=w.get("gram_s"), tm=tm,
+                      nchunk_ready=nready)
         ops.gemm1x1(mfold, qkv[:, 2 * C:], x, C, C, res=x, bias=w["wout_b"], w_bs=mfold_n, split=s_fold)
         ops.gdfn_fused(w["gdfn_f"], x, alt, C, hid, ln_mode=blk.norm2.mode, bias=w["pout_b"])
         return alt

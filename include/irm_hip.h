@@ -228,6 +228,16 @@ int irm_qkv_dw_fused_tm_f16x3_f32(const float* rec, const float* x, long x_bs, f
  * (~40 % fewer LDS reads per stage), q, k stored 16 bytes at a time. */
 int irm_qkv_dw_cm_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, int ln_mode, float eps,
                             float inv_s1, int B, int C, int H, int W, int x_tm, int v_tm, irm_stream_t stream);
+/* irm_qkv_gram_cm_f16x3_f32 (round 3): irm_qkv_dw_cm_f16x3_f32 for C = 48 with ONE head (the full-resolution encoder level)
+ * with the Gram pass inside: q and k are never written - the stencil outputs are scaled by gscale[channel] (the powers of two
+ * of irm_mdta_gram_f16x3_f32, [2C]), split into fp16 hi/lo and multiplied on the matrix cores, per chunk of 4 consecutive
+ * tiles of an image one partial record [48 x 48 Gram | 48 |q|^2 | 48 |k|^2] goes to part [B][H W / 1024][2400] (the format of
+ * irm_mdta_gram_*: irm_mdta_finalize_* reduces it with nchunk = H W / 1024); v as in irm_qkv_dw_cm_f16x3_f32.  The chunks are
+ * fixed sets of tiles of one image, so the result does not depend on the batch.  (H / 8) (W / 32) % 4 == 0.
+ * Replaces qkv_dwconv(qkv(norm1(x))) + the Gram / norm part of Attention.forward (restormer.py:105-106, 116-123). */
+int irm_qkv_gram_cm_f16x3_f32(const float* rec, const float* x, long x_bs, float* y, long y_bs, const float* gscale, float* part,
+                              int ln_mode, float eps, float inv_s1, int B, int C, int H, int W, int x_tm, int v_tm,
+                              irm_stream_t stream);
 /* irm_attn_gdfn_fused_f16x3_f32 (round 3): the last step of the attention branch inside the GDFN kernel's prologue,
  *   x' = x + bias_o + Mfold[b] v          (restormer.py:131, 147: project_out(attn @ v) + x, Mfold by irm_mdta_finalize_frag_f16x3_f32)
  *   y  = x' + project_out(gelu_erf(dw(h)[:hid]) * dw(h)[hid:]) + bias2,  h = project_in(LN(x')) + b      (:76-93, 148)

@@ -312,6 +312,51 @@ def test_qk_tile_major_chain(dev, C, heads, H, W, B, f16):
     assert float((a0 - a1).abs().max()) <= 2e-6 and float((m0 - m1).abs().max()) <= 2e-6
 
 
+@pytest.mark.parametrize("H,W,B,x_tm", [(32, 32, 2, False), (16, 128, 1, True), (64, 64, 3, True)])
+def test_qkv_gram_cm_c48(dev, H, W, B, x_tm):
+    """qkv_gram_cm (C = 48, one head): v bit-identical to qkv_dw_fused, the attention matrix and the folded matrix as from
+    the tile-major q, k + Gram pass (other summation order: a few ulps); batch-independent (image 0 alone == image 0 of B)."""
+    C, heads = 48, 1
+    tag = f"qg{H}_{W}"
+    M, N = 3 * C, H * W
+    x = rnd(tag + "x", (B, C, H, W), -1.5, 2.0).to(dev)
+    lnw, lnb = rnd(tag + "lw", (C,), 0.5, 1.5), rnd(tag + "lb", (C,), -0.2, 0.2)
+    w, dw_w = rnd(tag + "w", (M, C), -0.3, 0.3), rnd(tag + "dw", (M, 9), -0.4, 0.4)
+    pk = _hip.pack_qkv_fused(w.to(dev), None, dw_w, None, lnw, lnb)
+    gs = _hip.gram_scales(w.view(M, C, 1, 1), None, dw_w.view(M, 1, 3, 3), None, lnw, lnb, True).to(dev)
+    temp, wout = rnd(tag + "t", (heads,), 2.0, 6.0).to(dev), rnd(tag + "wo", (C, C), -0.3, 0.3).to(dev)
+    assert ops.can_qkv_gram(C, heads, H, W)
+    xin = to_tm(x.cpu()).to(dev) if x_tm else x
+
+    def fold(fused, xi, nb):
+        qkv = torch.full((nb, M, H, W), 7.0, device=dev)
+        _, nchunk, rec = ops.mdta_plan(nb, C, heads, N)
+        nready = None
+        if fused:
+            nchunk = (H // 8) * (W // 32) // ops.QKV_GRAM_NCH
+            part = torch.full((nb * nchunk * rec,), float("nan"), device=dev)
+            nready = ops.qkv_gram_cm(pk, xi, qkv, gs, part, C, ln_mode=1, x_tm=x_tm, v_tm=True)
+            assert nready == nchunk
+            assert torch.all(qkv[:, :2 * C] == 7.0), "q, k must not be written"
+        else:
+            part = torch.full((nb * nchunk * rec,), float("nan"), device=dev)
+            ops.qkv_dw_fused(pk, xi, qkv, C, M, ln_mode=1, tm=True, x_tm=x_tm, v_tm=True)
+        gsum = torch.empty(nb * rec, device=dev)
+        mfold = torch.zeros(nb * ops.mfold_numel(C), device=dev)
+        attn = torch.empty(nb, heads, C, C, device=dev)
+        ops.mdta_fold(qkv, part, gsum, temp, wout, mfold, C, heads, attn=attn, gram_scale=gs, tm=True, nchunk_ready=nready)
+        return qkv[:, 2 * C:].cpu(), attn.cpu(), mfold.cpu()
+
+    v0, a0, m0 = fold(False, xin, B)
+    v1, a1, m1 = fold(True, xin, B)
+    assert torch.equal(v0, v1), "v differs from qkv_dw_fused"
+    assert float((a0 - a1).abs().max()) <= 2e-6 and float((m0 - m1).abs().max()) <= 2e-6, \
+        (float((a0 - a1).abs().max()), float((m0 - m1).abs().max()))
+    if B > 1:
+        _, a2, m2 = fold(True, xin[:1].contiguous(), 1)
+        assert torch.equal(a2[0], a1[0]) and torch.equal(m2.view(-1), m1.view(B, -1)[0]), "depends on the batch"
+
+
 def _logu(name, shape, lo, hi):
     """log-uniform magnitudes in [lo, hi] with random signs (trained checkpoints: weights over many decades)."""
     u = rnd(name, shape, 0.0, 1.0)
