@@ -157,7 +157,11 @@ __global__ __launch_bounds__(512, 2) void gdfn_tail_kernel(TailArgs a) {
         auto load_h = [&](int s) {
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
+#ifdef FT_NO_LOAD                                  // (diagnostic: the kernel without its HBM reads of h)
+                const float* src = ft_zero_page;
+#else
                 const float* src = goff[k] >= 0 ? Hh + goff[k] + (s >> 2) * (256 * 64) + (s & 3) * 16 : ft_zero_page;
+#endif
                 hreg[k] = *reinterpret_cast<const f32x4*>(src);
             }
         };
