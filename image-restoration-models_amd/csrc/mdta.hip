@@ -764,8 +764,13 @@ static int mdta_finalize(const float* part, float* gsum, const float* temperatur
     if (C % heads || (long)B * heads > 65535) return IRM_EINVAL;
     const int c = C / heads;
     const int rec = c * c + 2 * c;
-    const int zsplit = 8;
-    const size_t lds = ((size_t)rec + (size_t)((C + zsplit - 1) / zsplit) * c) * sizeof(float);
+    // output rows split over zsplit workgroups per (image, head), each repeating the (cheap) softmax: 8, or fewer when that is
+    // more than two rounds of the chip (C = 384, 8 heads, 24 tiles: 1536 workgroups of 1024 threads took 56 us; 384 take 25).
+    // The result does not depend on the split (every output element is the same dot product).
+    auto lds_of = [&](int z) { return ((size_t)rec + (size_t)((C + z - 1) / z) * c) * sizeof(float); };
+    int zsplit = 8;
+    while (zsplit > 1 && (long)B * heads * zsplit > 512 && lds_of(zsplit / 2) <= 64 * 1024) zsplit >>= 1;
+    const size_t lds = lds_of(zsplit);
     if (lds > 64 * 1024) return IRM_EINVAL;
     hipLaunchKernelGGL(mdta_reduce_kernel, dim3((rec + 63) / 64, B * heads), dim3(256), 0, stream, part, gsum,
                        rec, nchunk);
