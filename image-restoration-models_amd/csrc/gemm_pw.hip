@@ -456,29 +456,19 @@ __global__ __launch_bounds__(256, (PT == 2 && NS == 3) ? 3 : 2) void gemm_ring_k
                 bh[c] = *reinterpret_cast<const irm_h4*>(wb + c * 256 + lane * 2);
                 bl[c] = *reinterpret_cast<const irm_h4*>(wb + c * 256 + 128 + lane * 2);
             }
-            // Two sweeps over the PT x CT independent accumulators (no MFMA waits on the one before it).  The K = 32 form takes
-            // the cycles of the K = 16 one (tools/probes/mfma_rate.hip: same ticks per instruction, 1716 vs 880 TFLOP/s over the
-            // chip), and the k index of an MFMA is a sum over (lane group, element) - any pairing the two operands agree on is
-            // valid - so the two SMALL products of the stage ride in one K = 32 instruction,
-            //     [x_lo | x_hi] . [W_hi | W_lo] = x_lo W_hi + x_hi W_lo,
-            // and x_hi W_hi follows as a K = 16 one on the halves of the same register tuples: 2 instead of 3 instruction slots
-            // per product, small terms still first.
-            typedef _Float16 pw_h8 __attribute__((ext_vector_type(8)));
-            pw_h8 ax[PT], bw[CT];
-#pragma unroll
-            for (int p = 0; p < PT; ++p) ax[p] = __builtin_shufflevector(al[p], ah[p], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-            for (int c = 0; c < CT; ++c) bw[c] = __builtin_shufflevector(bh[c], bl[c], 0, 1, 2, 3, 4, 5, 6, 7);
+            // three sweeps over the PT x CT independent accumulators (no MFMA waits on the one before it)
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
-                for (int p = 0; p < PT; ++p) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ax[p], bw[c], acc[p][c], 0, 0, 0);
+                for (int p = 0; p < PT; ++p) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(al[p], bh[c], acc[p][c], 0, 0, 0);
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
-                for (int p = 0; p < PT; ++p)
-                    acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_shufflevector(ax[p], ax[p], 4, 5, 6, 7),
-                                                                     __builtin_shufflevector(bw[c], bw[c], 0, 1, 2, 3), acc[p][c], 0, 0, 0);
+                for (int p = 0; p < PT; ++p) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[p], bl[c], acc[p][c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[p], bh[c], acc[p][c], 0, 0, 0);
         } else {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {

@@ -246,6 +246,9 @@ class Restormer(nn.Module):
         for name in ("reduce_chan_level3", "reduce_chan_level2") + (("skip_conv",) if self.dual_pixel_task else ()):
             pk[name] = _hip.pack_gemm_weight(getattr(self, name).weight)
             pk[name + "_b"] = f32(getattr(self, name).bias)
+            # (un-normalised input: the emulated GEMM scales it by 2^-4 and saturates, as for project_out)
+            if self._split and name != "skip_conv" and _hip.split_is_safe(getattr(self, name).weight):
+                pk[name + "_s"] = _hip.pack_gemm_weight_split(getattr(self, name).weight)
         self._packed, self._packed_key = pk, key
         return pk
 
@@ -492,10 +495,14 @@ class Restormer(nn.Module):
         self._run_stage("latent", pk, lat)
 
         ops.conv3x3(pk["up4_3"], lat, cat3[:, :d3], d4, d4 * 2, store_mode=2)
-        ops.gemm1x1(pk["reduce_chan_level3"], cat3, dec3, d3, 2 * d3, bias=pk["reduce_chan_level3_b"])
+        rs3 = "reduce_chan_level3_s" in pk and (H3 * W3) % 4 == 0
+        ops.gemm1x1(pk["reduce_chan_level3" + ("_s" if rs3 else "")], cat3, dec3, d3, 2 * d3, bias=pk["reduce_chan_level3_b"],
+                    split=rs3)
         self._run_stage("decoder_level3", pk, dec3)
         ops.conv3x3(pk["up3_2"], dec3, cat2[:, :d2], d3, d3 * 2, store_mode=2)
-        ops.gemm1x1(pk["reduce_chan_level2"], cat2, dec2, d2, 2 * d2, bias=pk["reduce_chan_level2_b"])
+        rs2 = "reduce_chan_level2_s" in pk and (H2 * W2) % 4 == 0
+        ops.gemm1x1(pk["reduce_chan_level2" + ("_s" if rs2 else "")], cat2, dec2, d2, 2 * d2, bias=pk["reduce_chan_level2_b"],
+                    split=rs2)
         self._run_stage("decoder_level2", pk, dec2)
         ops.conv3x3(pk["up2_1"], dec2, cat1[:, :d1], d2, d2 * 2, store_mode=2)
         # (decoder_level1 and refinement work on the same tensor: one chain, no planar round trip between them)

@@ -28,7 +28,27 @@ __global__ __launch_bounds__(256) void probe(float* out, long long* cyc, int ite
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// fp16 SUBNORMAL inputs: A = 2^-16 everywhere (subnormal: the smallest normal fp16 is 2^-14), B = 1: D = K 2^-16 if honoured, 0 if flushed
+__global__ void denorm_probe(float* out) {
+    const _Float16 sub = (_Float16)1.52587890625e-05f, one = (_Float16)1.0f;
+    h4 a4 = {sub, sub, sub, sub}, b4 = {one, one, one, one};
+    h8 a8 = {sub, sub, sub, sub, sub, sub, sub, sub}, b8 = {one, one, one, one, one, one, one, one};
+    f4 z = {0, 0, 0, 0};
+    const f4 d16 = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, z, 0, 0, 0);
+    const f4 d32 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, z, 0, 0, 0);
+    const f4 e32 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b8, a8, z, 0, 0, 0);        // subnormal on the B side
+    if (threadIdx.x == 0) { out[0] = d16[0]; out[1] = d32[0]; out[2] = e32[0]; }
+}
+
 int main() {
+    {
+        float* o; hipMalloc(&o, 16);
+        hipLaunchKernelGGL(denorm_probe, dim3(1), dim3(64), 0, 0, o);
+        float h[3]; hipMemcpy(h, o, 12, hipMemcpyDeviceToHost);
+        printf("subnormal fp16 inputs (2^-16 x 1 summed over K): 16x16x16_f16 -> %g (expected %g), 16x16x32_f16 -> %g / %g (expected %g)\n",
+               h[0], 16 * 1.52587890625e-05, h[1], h[2], 32 * 1.52587890625e-05);
+    }
+
     float* out; long long* cyc;
     hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 256 * 8);
     const int iters = 2000;
