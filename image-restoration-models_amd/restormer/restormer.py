@@ -495,12 +495,12 @@ class Restormer(nn.Module):
         self._run_stage("latent", pk, lat)
 
         ops.conv3x3(pk["up4_3"], lat, cat3[:, :d3], d4, d4 * 2, store_mode=2)
-        rs3 = "reduce_chan_level3_s" in pk and (H3 * W3) % 4 == 0
+        rs3 = "reduce_chan_level3_s" in pk and (H3 * W3) % 4 == 0 and not os.environ.get("IRM_NO_RC_SPLIT")
         ops.gemm1x1(pk["reduce_chan_level3" + ("_s" if rs3 else "")], cat3, dec3, d3, 2 * d3, bias=pk["reduce_chan_level3_b"],
                     split=rs3)
         self._run_stage("decoder_level3", pk, dec3)
         ops.conv3x3(pk["up3_2"], dec3, cat2[:, :d2], d3, d3 * 2, store_mode=2)
-        rs2 = "reduce_chan_level2_s" in pk and (H2 * W2) % 4 == 0
+        rs2 = "reduce_chan_level2_s" in pk and (H2 * W2) % 4 == 0 and not os.environ.get("IRM_NO_RC_SPLIT")
         ops.gemm1x1(pk["reduce_chan_level2" + ("_s" if rs2 else "")], cat2, dec2, d2, 2 * d2, bias=pk["reduce_chan_level2_b"],
                     split=rs2)
         self._run_stage("decoder_level2", pk, dec2)
