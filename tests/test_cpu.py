@@ -468,6 +468,21 @@ def test_apply_fusion_host_side_packing():
     assert torch.equal(slots(r1), slots(r0)[..., chan])
 
 
+def test_qkv_gram_plan_matches_the_record_layout_of_the_header():
+    """Host side of irm_qkv_gram_cm_f16x3_f32: C = 48 with one head and whole chunks of 4 tiles only; the records per image it
+    announces to mdta_fold are H W / 1024 (include/irm_hip.h), each of the Gram pass's own size."""
+    from irm_amd import ops
+    assert ops.QKV_GRAM_NCH * 256 == 1024
+    assert ops.can_qkv_gram(48, 1, 512, 512) and ops.can_qkv_gram(48, 1, 32, 32)
+    assert not ops.can_qkv_gram(96, 1, 512, 512) and not ops.can_qkv_gram(48, 2, 512, 512)
+    assert not ops.can_qkv_gram(48, 1, 40, 96)          # 15 tiles: no whole chunks
+    assert not ops.can_qkv_gram(48, 1, 36, 64) and not ops.can_qkv_gram(48, 1, 32, 48)
+    _, _, rec = ops.mdta_plan(2, 48, 1, 512 * 512)
+    assert rec == 48 * 48 + 2 * 48
+    sig = _hip.SIGNATURES["irm_qkv_gram_cm_f16x3_f32"]
+    assert len(sig) == 17                               # the header's 16 arguments + the stream
+
+
 def test_fullsize_frame_fixture_is_self_consistent():
     """tests/golden/restormer_fullsize_frame.npz (the reference's run_model_inference on bench frame 0): the stored
     sha256 and PSNR are those of the stored uint8 frame against the regenerated synthetic target, and the input it
