@@ -23,9 +23,10 @@ class KernelTimer:
     logs the call's algorithmic FLOPs and compulsory bytes (inputs read once,
     outputs written once, fp32).  ``summary()`` synchronises and aggregates."""
 
-    def __init__(self, detail=False):
+    def __init__(self, detail=False, only=None):
         self.records = []          # (kernel, start_event, end_event, flops, bytes)
         self.detail = detail       # key the summary by kernel + shape tag
+        self.only = None if only is None else frozenset(only)   # time these kernel groups only (the others launch plainly)
         self._chain = {}           # stream -> end event of the previous timed launch on it
         self._done = {}            # totals of the records already folded (their events released)
         self._since = 0
@@ -55,6 +56,10 @@ class KernelTimer:
         # back-to-back launches on one stream share an event (end of one = start of the next): half the
         # event packets between the kernels, i.e. half of the timer's own cost in the timed region
         sid = torch.cuda.current_stream().cuda_stream
+        if self.only is not None and kernel not in self.only:
+            fn()
+            self._chain.pop(sid, None)             # un-timed work in between: the next timed launch records its own start
+            return
         e0 = self._chain.get(sid)
         if e0 is None:
             e0 = torch.cuda.Event(enable_timing=True)
