@@ -746,6 +746,28 @@ def test_conv3x3_thin(dev, ci, co, H, W, B, bias, relu1, res_mode, relu2):
     assert torch.all(got[:, 0] == 5.0) and torch.all(got[:, -1] == 5.0)
 
 
+def test_kernel_timer_only_times_the_selected_group(dev):
+    """ops.KernelTimer(only=...): bench.py's timed steps carry events around the roofline kernel only - the other launches run
+    plainly (and give the same results), the selected group is timed launch by launch."""
+    B, C, H, W = 2, 32, 16, 32
+    x = rnd("kt_x", (B, C, H, W)).to(dev)
+    w9 = rnd("kt_w", (C, 9), -0.4, 0.4).to(dev)
+    stats = torch.empty(B, 2, H * W, device=dev)
+    y0, y1 = torch.empty_like(x), torch.empty_like(x)
+    ops.dwconv3x3(x, w9, y0)
+    timer, ops.TIMER = ops.TIMER, ops.KernelTimer(only={"dwconv3x3"})
+    try:
+        ops.ln_stats(x, stats)                      # not selected: no record
+        ops.dwconv3x3(x, w9, y1)
+        ops.ln_stats(x, stats)
+        ops.dwconv3x3(x, w9, y1)
+        s = ops.TIMER.summary()
+    finally:
+        ops.TIMER = timer
+    assert list(s) == ["dwconv3x3"] and s["dwconv3x3"]["launches"] == 2 and s["dwconv3x3"]["ms"] > 0.0
+    assert torch.equal(y0, y1)
+
+
 # --------------------------------------------------------------------------- no writes outside the output
 def _guarded(dev, shape, pad=1 << 14):
     n = int(np.prod(shape))
